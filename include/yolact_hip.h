@@ -1,0 +1,220 @@
+/*
+ * yolact_hip.h — C ABI of the MI355X-native YOLACT inference library (libyolact_hip.so).
+ *
+ * This is the drop-in boundary for the reference's L2 layer: it stands in for the
+ * TFLite interpreter + EdgeTPU delegate that /root/reference/src/yolact.rs drives.  Each entry
+ * point names the reference call (file:line, relative to the reference checkout) it replaces.
+ * Plain C types only; no exceptions cross the boundary; no global state; every handle owns a
+ * private HIP stream and binds its device on every entry, so calls may arrive from different OS
+ * threads over time (tokio worker migration, src/main.rs:63-75) but never concurrently per handle.
+ *
+ * Status convention: every function returning int returns YH_OK (0) on success and a negative
+ * YH_E* code otherwise; yh_last_error(h) then holds a human-readable message.  The reference
+ * `.expect()`s every failure (src/yolact.rs:20,25,27,29,35,163); the host shim decides to panic.
+ */
+#ifndef YOLACT_HIP_H
+#define YOLACT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_ABI_VERSION 1
+
+enum {
+    YH_OK = 0,
+    YH_EINVAL = -1,     /* bad argument */
+    YH_EHIP = -2,       /* HIP runtime error */
+    YH_ENOMEM = -3,
+    YH_EWEIGHTS = -4,   /* weight blob does not match the architecture */
+    YH_ESTATE = -5,     /* call out of order (e.g. invoke before weights) */
+    YH_EDIVERGE = -6,   /* strict compat: the reference's flood fill would not terminate here
+                           (src/yolact.rs:57-78) */
+    YH_EOVERFLOW = -7   /* a bounded device list overflowed (never silently truncated) */
+};
+
+/* Backbone depth of the YOLACT architecture. */
+enum { YH_BACKBONE_R50 = 50, YH_BACKBONE_R101 = 101 };
+
+/* Output tensor element kinds; mirrors tflite::context::ElementKind as used at src/yolact.rs:171-186. */
+enum { YH_KIND_F32 = 1, YH_KIND_U8 = 3, YH_KIND_F16 = 10 };
+
+/* Reference-compat behaviour of yh_classify_frame_u32. */
+enum {
+    YH_COMPAT_STRICT = 0, /* bit-for-bit what src/yolact.rs computes, quirks A8'/A9 included; returns
+                             YH_EDIVERGE where the reference would loop forever */
+    YH_COMPAT_SANE = 1    /* 4-connected component ids, `|` packing: what the author meant */
+};
+
+typedef struct yh_engine yh_engine; /* opaque; replaces struct Yolact<'a> (src/yolact.rs:13-15) */
+
+typedef struct yh_config {
+    int32_t abi_version;   /* must be YH_ABI_VERSION */
+    int32_t device;        /* HIP device ordinal */
+    int32_t backbone;      /* YH_BACKBONE_R50 | YH_BACKBONE_R101 */
+    int32_t input_size;    /* square input: 550 (YOLACT-550), 700, 224 (reference tile, yolact.rs:143-144) ... */
+    int32_t max_batch;     /* frames per invoke the arena is sized for (1..256) */
+    int32_t num_classes;   /* incl. background; 81 (src/yolact.rs:108: chunks(81)) */
+    int32_t top_k;         /* per-class candidates kept before Fast-NMS (200) */
+    int32_t max_dets;      /* detections kept per frame (100) */
+    float conf_thresh;     /* 0.05 */
+    float nms_thresh;      /* 0.5 */
+    int32_t use_graph;     /* 1: capture the forward in a hipGraph after the first invoke */
+    int32_t reserved[8];   /* zero */
+} yh_config;
+
+/* Mirrors tflite TensorInfo {name, element_kind, dims, params{scale, zero_point}} as read at
+ * src/yolact.rs:150 and :170-175. dims are NHWC-ordered, dims[0] = current batch. */
+typedef struct yh_tensor_info {
+    const char* name;
+    int32_t kind;      /* YH_KIND_* */
+    int32_t ndims;
+    int32_t dims[4];
+    float scale;       /* 1.0 for float tensors */
+    int32_t zero_point;/* 0 for float tensors */
+} yh_tensor_info;
+
+/* One detection of the fused path (absent in the reference, src/yolact.rs:3-5). */
+typedef struct yh_detection {
+    int32_t class_id;   /* 0..num_classes-2 (foreground index; background removed) */
+    int32_t prior;      /* prior index the detection came from */
+    float score;
+    float box[4];       /* x1,y1,x2,y2 relative to the frame, unclamped */
+} yh_detection;
+
+/* ---- life cycle --------------------------------------------------------------------------- */
+
+/* edgetpu::version() (src/scene.rs:62). Static string. */
+const char* yh_version(void);
+
+/* Fills *cfg with the YOLACT-550 R50 defaults. */
+void yh_default_config(yh_config* cfg);
+
+/* FlatBufferModel::build_from_file + InterpreterBuilder::new/build + EdgeTpuContext::open_device +
+ * set_num_threads + allocate_tensors (src/yolact.rs:18-35): builds the layer table for cfg,
+ * allocates the whole activation arena and a private stream on cfg->device. No weights yet. */
+int yh_create(const yh_config* cfg, yh_engine** out);
+void yh_destroy(yh_engine* h);
+const char* yh_last_error(const yh_engine* h); /* h may be NULL: last create error of this thread */
+
+/* ---- weights ------------------------------------------------------------------------------ */
+
+/* Size in bytes of the canonical weight blob (DESIGN.md §Weight blob) for this architecture. */
+size_t yh_weights_nbytes(const yh_engine* h);
+/* Writes the seeded synthetic blob (He-scaled uniform, BN folded to bias) into host memory. The
+ * reference's model file is absent (.MISSING_LARGE_BLOBS:1-2); this is its stand-in. */
+int yh_weights_generate(const yh_engine* h, uint64_t seed, void* blob_host, size_t nbytes);
+/* Loads a canonical blob from host memory: validates the per-layer header, repacks to the kernels'
+ * padded KRSC panels on device. Replaces build_from_file("data/FRC_model_edgetpu.tflite"), yolact.rs:18-20. */
+int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes);
+/* Same, blob already in device memory on this handle's device (e.g. the receive buffer of an RCCL
+ * broadcast from rank 0 over xGMI: SURVEY.md §8e). */
+int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
+
+/* ---- interpreter-shaped surface (lets classify_tile, src/yolact.rs:133-190, port unchanged) -- */
+
+/* interpreter.inputs()[0] + tensor_info(..).dims (src/yolact.rs:149-150): {max_batch,S,S,3}. */
+int yh_input_dims(const yh_engine* h, int32_t dims[4]);
+/* tensor_data_mut(in).copy_from_slice (src/yolact.rs:161-162): copies n frames of u8 RGB NHWC
+ * from host memory into the engine-owned input buffer. */
+int yh_set_input_u8(yh_engine* h, const uint8_t* rgb_host, int32_t n_frames);
+/* Same with frames already resident in device memory (bench path: inputs in HBM). */
+int yh_set_input_u8_device(yh_engine* h, const uint8_t* rgb_dev, int32_t n_frames);
+/* interpreter.invoke() (src/yolact.rs:163): the network forward for the frames last set.
+ * Asynchronous on the handle's stream; yh_sync or any output read waits for it. */
+int yh_invoke(yh_engine* h);
+int yh_sync(yh_engine* h);
+/* interpreter.outputs().len() / tensor_info(output) (src/yolact.rs:166,170). Output order:
+ *   0 loc    [n,P,4]  f16   box regressions
+ *   1 conf   [n,P,C]  f16   class logits (pre-softmax)
+ *   2 mask   [n,P,32] f16   tanh mask coefficients
+ *   3 proto  [n,Hp,Wp,32] f16 prototypes (ReLU)
+ *   4 cells  [n,H3,W3,C] f32 class logits of anchor 0 on the stride-8 level: for a 224 input this
+ *            is the 28*28*81 tensor the reference reads as results[4] (src/yolact.rs:91,108). */
+int yh_output_count(const yh_engine* h);
+int yh_output_info(const yh_engine* h, int32_t index, yh_tensor_info* info);
+/* tensor_data::<u8|f32>(output) (src/yolact.rs:173,180): copies output `index` to host memory
+ * converted to f32 (the reference dequantises to Vec<f32> at :176-181). nfloats = capacity. */
+int yh_output_read_f32(yh_engine* h, int32_t index, float* dst_host, size_t nfloats);
+/* Device pointer of the engine-owned output buffer; valid until the next yh_invoke. */
+const void* yh_output_device_ptr(const yh_engine* h, int32_t index);
+
+/* ---- fused detection path (north_star "Yolact::evaluate") ---------------- */
+
+/* Forward + softmax/threshold + per-class top-k + box decode + Fast-NMS + top max_dets +
+ * mask assembly (mask-coeff x prototypes, logit>0 == sigmoid>0.5, box crop) for the frames last
+ * set. Asynchronous; results are read with yh_read_detections. */
+int yh_evaluate(yh_engine* h);
+/* Copies results of the last yh_evaluate for frame `frame`: counts[0] = number of detections d,
+ * dets[0..d), and (if masks != NULL) d binary masks of Hp*Wp bytes each (0/1). */
+int yh_read_detections(yh_engine* h, int32_t frame, int32_t* count, yh_detection* dets,
+                       int32_t dets_capacity, uint8_t* masks, size_t masks_capacity);
+int yh_proto_dims(const yh_engine* h, int32_t dims[2]); /* {Hp, Wp} */
+int yh_num_priors(const yh_engine* h);
+/* Copies the P x 4 prior table (cx,cy,w,h) to host memory. */
+int yh_read_priors(const yh_engine* h, float* dst_host, size_t nfloats);
+
+/* ---- reference-compat path: Yolact::classify (src/yolact.rs:39-41, :192-234) --------------- */
+
+/* In-place classify of one packed camera frame: `frame` holds width*height u32 pixels packed
+ * r<<24|g<<16|b<<8 (src/scene.rs:86). Runs, all on device: unpack (yolact.rs:195-201), Triangle
+ * resize to (2S x S) (yolact.rs:208), two S x S tiles as one batch of 2 (yolact.rs:213-217),
+ * forward, output-4 gated argmax (yolact.rs:108-118), ids (yolact.rs:52-88), pack + x8 nearest
+ * upsample (yolact.rs:127-128), stitch (yolact.rs:219-220), Triangle resize back (yolact.rs:231)
+ * and repack (yolact.rs:233). Requires input_size*2 x input_size tiles, input_size % 8 == 0
+ * (224 for the reference) and max_batch >= 2. Synchronous (the reference's classify is). */
+int yh_classify_frame_u32(yh_engine* h, uint32_t* frame_host, int32_t width, int32_t height,
+                          int32_t compat_mode);
+/* The post-network half only, on caller-provided output-4 logits (n_tiles x cells x C f32, host):
+ * exactly `postprocess` (src/yolact.rs:90-131) per tile. out: n_tiles x (S*S) u32. Lets the
+ * reference's integer logic be checked bit-for-bit without a network in the loop. */
+int yh_postprocess_cells(yh_engine* h, const float* cells_host, int32_t n_tiles, uint32_t* out_host,
+                         int32_t compat_mode);
+/* Device Triangle resize of an RGB8 image, the `image` crate call at src/yolact.rs:208,:231. */
+int yh_resize_triangle_rgb8(yh_engine* h, const uint8_t* src_host, int32_t sw, int32_t sh,
+                            uint8_t* dst_host, int32_t dw, int32_t dh);
+
+/* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
+
+/* Number of kernel launches in one forward(+tail if with_tail) for the current batch. */
+int yh_profile_launch_count(const yh_engine* h, int32_t with_tail);
+/* Runs `reps` forwards with a hipEvent pair around every launch on the handle's own stream and
+ * writes, per launch: mean milliseconds, algorithmic FLOPs and algorithmic bytes, and a static
+ * name ("kernel_symbol:layer"). Arrays must hold yh_profile_launch_count entries. */
+int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, double* flops,
+                   double* bytes, const char** names);
+/* Times `steps` back-to-back yh_evaluate (or yh_invoke if !with_tail) calls with one hipEvent
+ * pair on the handle's stream; returns total milliseconds in *ms_total. */
+int yh_time_steps(yh_engine* h, int32_t with_tail, int32_t steps, float* ms_total);
+/* Algorithmic conv FLOPs of one frame for this architecture (2 x MAC, convs only). */
+double yh_flops_per_frame(const yh_engine* h);
+
+/* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */
+
+/* One NHWC f16 convolution on the MFMA implicit-GEMM kernel with fused bias (+residual) (+act).
+ * All pointers are host memory; the call stages, runs and copies back (test-only convenience).
+ * x: [n,h,w,cin] f16 bits; w: [cout,kh,kw,cin] f16 bits; bias: [cout] f32; residual (nullable):
+ * [n,ho,wo,cout] f16 bits; y: [n,ho,wo,cout] f16 bits. act: 0 none, 1 relu, 2 tanh. */
+int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin,
+                     const uint16_t* w, const float* bias, int32_t cout, int32_t kh, int32_t kw,
+                     int32_t stride, int32_t pad, const uint16_t* residual, int32_t act,
+                     uint16_t* y);
+/* Bilinear resize (align_corners = false) of an NHWC f16 tensor, optional accumulate into dst. */
+int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t c,
+                       int32_t ho, int32_t wo, uint16_t* y);
+/* 3x3 stride-2 pad-1 max pool of an NHWC f16 tensor. */
+int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww,
+                           int32_t c, uint16_t* y);
+/* Detection tail alone on caller-provided head outputs (host f16 bits, layouts as outputs 0..3)
+ * for n frames; results are then read with yh_read_detections. Lets the tail be checked
+ * bit-for-bit against the oracle on identical inputs. */
+int yh_op_detect(yh_engine* h, const uint16_t* loc, const uint16_t* conf, const uint16_t* mask,
+                 const uint16_t* proto, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLACT_HIP_H */

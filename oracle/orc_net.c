@@ -1,0 +1,535 @@
+/*
+ * orc_net.c — CPU restatement of the YOLACT network forward. TEST INFRASTRUCTURE.
+ *
+ * PARITY UNPINNED against the reference: the reference executes its network inside the tflite
+ * interpreter (call site /root/reference/src/yolact.rs:163) on a model file that is absent from
+ * the checkout (.MISSING_LARGE_BLOBS:1-2). This file restates the published YOLACT architecture
+ * (Bolya et al., ICCV 2019) as frozen in DESIGN.md §Spec; its primitives are pinned against torch
+ * CPU by tests/test_oracle_vs_torch.py. Written independently of the HIP engine: different loop
+ * order (direct convolution, weights transposed to [kh*kw*cin][cout]), f32 storage, no shared code.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ binary16 rounding (RNE) */
+uint16_t orc_f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);       /* NaN */
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);      /* >= 65520 -> inf (incl. inf) */
+    if (x < 0x38800000u) {                                        /* |f| < 2^-14: subnormal half */
+        float a;
+        memcpy(&a, &x, 4);
+        float scaled = a * 16777216.0f;                           /* exact: units of 2^-24 */
+        return (uint16_t)(sign | (uint16_t)lrintf(scaled));       /* RNE; 1024 carries into exp=1 */
+    }
+    x += 0xFFFu + ((x >> 13) & 1u);                               /* RNE on the 13 dropped bits */
+    return (uint16_t)(sign | (uint16_t)((x - 0x38000000u) >> 13));
+}
+
+float orc_f16_bits_to_f32(uint16_t b) {
+    uint32_t sign = (uint32_t)(b & 0x8000u) << 16, e = (b >> 10) & 0x1Fu, m = b & 0x3FFu, x;
+    if (e == 0) {
+        float v = (float)m * (1.0f / 16777216.0f);
+        memcpy(&x, &v, 4);
+        x |= sign;
+    } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float r;
+    memcpy(&r, &x, 4);
+    return r;
+}
+
+float orc_f16_round(float v) { return orc_f16_bits_to_f32(orc_f32_to_f16_bits(v)); }
+
+/* ------------------------------------------------------------------ tensors */
+typedef struct {
+    char name[24];
+    int n, h, w, c;
+    float* d;
+} tensor;
+
+typedef struct {
+    int cout, cin, kh, kw;
+    float* wt;   /* [kh*kw*cin][cout] */
+    float* bias; /* [cout] */
+} convw;
+
+#define MAX_T 512
+struct orc_net {
+    orc_net_cfg cfg;
+    int nconv;
+    convw* convs;
+    int nt;
+    tensor t[MAX_T];
+    int lvl_h[5], lvl_w[5], P, hp, wp;
+    float* priors;
+    double flops;
+    int nthreads, f16;
+};
+
+/* ------------------------------------------------------------------ canonical conv table */
+typedef struct { int cout, cin, k; float gain; int kind; } convspec; /* kind: 0 plain, 1 conf */
+
+static int blocks_of(int backbone, int layer) {
+    static const int r50[4] = { 3, 4, 6, 3 }, r101[4] = { 3, 4, 23, 3 };
+    return backbone == 101 ? r101[layer] : r50[layer];
+}
+
+/* Fills specs (if non-NULL) and returns the number of convs, in DESIGN.md §Weight-blob order. */
+static int conv_table(const orc_net_cfg* cfg, convspec* s) {
+    int n = 0;
+#define ADD(co, ci, kk, g, kd) do { if (s) { s[n].cout = (co); s[n].cin = (ci); s[n].k = (kk); s[n].gain = (g); s[n].kind = (kd); } ++n; } while (0)
+    ADD(64, 3, 7, 1.0f, 0);
+    int inc = 64;
+    for (int L = 0; L < 4; ++L) {
+        int planes = 64 << L;
+        for (int b = 0; b < blocks_of(cfg->backbone, L); ++b) {
+            ADD(planes, inc, 1, 1.0f, 0);
+            ADD(planes, planes, 3, 1.0f, 0);
+            ADD(planes * 4, planes, 1, 0.3f, 0);
+            if (b == 0) ADD(planes * 4, inc, 1, 1.0f, 0);
+            inc = planes * 4;
+        }
+    }
+    ADD(256, 2048, 1, 0.2f, 0); ADD(256, 1024, 1, 0.2f, 0); ADD(256, 512, 1, 0.2f, 0); /* lat C5,C4,C3 */
+    for (int i = 0; i < 3; ++i) ADD(256, 256, 3, 0.7f, 0);                              /* pred P5,P4,P3 */
+    for (int i = 0; i < 2; ++i) ADD(256, 256, 3, 1.0f, 0);                              /* down P6,P7 */
+    for (int i = 0; i < 4; ++i) ADD(256, 256, 3, 1.0f, 0);                              /* proto 0..3 */
+    ADD(32, 256, 1, 1.0f, 0);                                                           /* proto out */
+    ADD(256, 256, 3, 1.0f, 0);                                                          /* head trunk */
+    ADD(12, 256, 3, 0.1f, 0);                                                           /* box */
+    ADD(3 * cfg->num_classes, 256, 3, 0.7f, 1);                                         /* conf */
+    ADD(96, 256, 3, 0.5f, 0);                                                           /* mask */
+#undef ADD
+    return n;
+}
+
+static size_t pad16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+
+size_t orc_weights_nbytes(const orc_net_cfg* cfg) {
+    int n = conv_table(cfg, NULL);
+    convspec* s = (convspec*)malloc((size_t)n * sizeof(convspec));
+    conv_table(cfg, s);
+    size_t tot = 16;
+    for (int i = 0; i < n; ++i)
+        tot += 16 + pad16((size_t)s[i].cout * s[i].k * s[i].k * s[i].cin * 2) + pad16((size_t)s[i].cout * 4);
+    free(s);
+    return tot;
+}
+
+static uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+/* uniform in [-1,1) with 24 bits, exactly representable */
+static float unit_rand(uint64_t seed, uint64_t conv, uint64_t stream, uint64_t e) {
+    uint64_t u = splitmix(splitmix(seed + conv * 1000003ull + stream) + e);
+    return ((float)(uint32_t)(u >> 40) - 8388608.0f) * (1.0f / 8388608.0f);
+}
+
+#define CONF_BG_BIAS 7.5f
+
+int orc_weights_generate(const orc_net_cfg* cfg, uint64_t seed, void* blob, size_t nbytes) {
+    if (nbytes != orc_weights_nbytes(cfg)) return -1;
+    int n = conv_table(cfg, NULL);
+    convspec* s = (convspec*)malloc((size_t)n * sizeof(convspec));
+    conv_table(cfg, s);
+    uint8_t* p = (uint8_t*)blob;
+    memset(p, 0, nbytes);
+    memcpy(p, "YHW1", 4);
+    uint32_t hdr[3] = { (uint32_t)n, (uint32_t)cfg->backbone, (uint32_t)cfg->num_classes };
+    memcpy(p + 4, hdr, 12);
+    p += 16;
+    for (int i = 0; i < n; ++i) {
+        uint32_t rec[4] = { (uint32_t)s[i].cout, (uint32_t)s[i].cin, (uint32_t)s[i].k, (uint32_t)s[i].k };
+        memcpy(p, rec, 16);
+        p += 16;
+        size_t ne = (size_t)s[i].cout * s[i].k * s[i].k * s[i].cin;
+        float fan_in = (float)(s[i].k * s[i].k * s[i].cin);
+        float a = s[i].gain * sqrtf(6.0f / fan_in);
+        uint16_t* w = (uint16_t*)p;
+        for (size_t e = 0; e < ne; ++e) w[e] = orc_f32_to_f16_bits(unit_rand(seed, (uint64_t)i, 0, e) * a);
+        p += pad16(ne * 2);
+        float* b = (float*)p;
+        for (int e = 0; e < s[i].cout; ++e) {
+            float v = unit_rand(seed, (uint64_t)i, 1, (uint64_t)e) * 0.1f;
+            if (s[i].kind == 1 && (e % cfg->num_classes) == 0) v = v + CONF_BG_BIAS;
+            b[e] = v;
+        }
+        p += pad16((size_t)s[i].cout * 4);
+    }
+    free(s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ primitives */
+#define PT 8
+#define KB 256
+
+static float act_apply(float v, int act) {
+    if (act == 1) return v > 0.0f ? v : 0.0f;
+    if (act == 2) return orc_spec_tanhf(v);
+    return v;
+}
+
+static void conv_core(const float* x, int n, int h, int w, int cin, const float* wt, const float* bias,
+                      int cout, int kh, int kw, int stride, int pad, const float* res, int act,
+                      int f16, int nthreads, float* y, int ho, int wo) {
+    long M = (long)n * ho * wo;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (long m0 = 0; m0 < M; m0 += PT) {
+        int np = (int)(M - m0 < PT ? M - m0 : PT);
+        int pn[PT], py[PT], px[PT];
+        for (int p = 0; p < np; ++p) {
+            long m = m0 + p;
+            pn[p] = (int)(m / ((long)ho * wo));
+            long rem = m % ((long)ho * wo);
+            py[p] = (int)(rem / wo) * stride - pad;
+            px[p] = (int)(rem % wo) * stride - pad;
+        }
+        for (int kb = 0; kb < cout; kb += KB) {
+            int kn = cout - kb < KB ? cout - kb : KB;
+            float acc[PT][KB];
+            for (int p = 0; p < np; ++p)
+                for (int k = 0; k < kn; ++k) acc[p][k] = 0.0f;
+            for (int r = 0; r < kh; ++r)
+                for (int s = 0; s < kw; ++s) {
+                    const float* xp[PT];
+                    int any = 0;
+                    for (int p = 0; p < np; ++p) {
+                        int iy = py[p] + r, ix = px[p] + s;
+                        xp[p] = (iy >= 0 && iy < h && ix >= 0 && ix < w)
+                                    ? x + (((size_t)pn[p] * h + iy) * w + ix) * cin : NULL;
+                        any |= xp[p] != NULL;
+                    }
+                    if (!any) continue;
+                    for (int c = 0; c < cin; ++c) {
+                        const float* wrow = wt + ((size_t)(r * kw + s) * cin + c) * cout + kb;
+                        for (int p = 0; p < np; ++p) {
+                            if (!xp[p]) continue;
+                            float xv = xp[p][c];
+                            float* ap = acc[p];
+                            for (int k = 0; k < kn; ++k) ap[k] += xv * wrow[k];
+                        }
+                    }
+                }
+            for (int p = 0; p < np; ++p) {
+                size_t o = (size_t)(m0 + p) * cout + kb;
+                for (int k = 0; k < kn; ++k) {
+                    float v = acc[p][k] + bias[kb + k];
+                    if (res) v = v + res[o + k];
+                    v = act_apply(v, act);
+                    y[o + k] = f16 ? orc_f16_round(v) : v;
+                }
+            }
+        }
+    }
+}
+
+static int out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+
+void orc_conv2d(const float* x, int n, int h, int w, int cin, const float* wk, const float* bias,
+                int cout, int kh, int kw, int stride, int pad, const float* residual, int act,
+                int f16_storage, int nthreads, float* y) {
+    /* transpose [cout][kh][kw][cin] -> [kh*kw*cin][cout] */
+    size_t K = (size_t)kh * kw * cin;
+    float* wt = (float*)malloc(K * cout * sizeof(float));
+    for (int o = 0; o < cout; ++o)
+        for (size_t k = 0; k < K; ++k) wt[k * cout + o] = wk[(size_t)o * K + k];
+    conv_core(x, n, h, w, cin, wt, bias, cout, kh, kw, stride, pad, residual, act, f16_storage,
+              nthreads, y, out_dim(h, kh, stride, pad), out_dim(w, kw, stride, pad));
+    free(wt);
+}
+
+/* Bilinear, align_corners=false (half-pixel centres), scale = in/out, source clamped at 0. */
+void orc_bilinear(const float* x, int n, int h, int w, int c, int ho, int wo, int f16, float* y) {
+    float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+    for (int b = 0; b < n; ++b)
+        for (int oy = 0; oy < ho; ++oy) {
+            float fy = ((float)oy + 0.5f) * sy - 0.5f;
+            if (fy < 0.0f) fy = 0.0f;
+            int y0 = (int)fy, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+            float ly = fy - (float)y0, hy = 1.0f - ly;
+            for (int ox = 0; ox < wo; ++ox) {
+                float fx = ((float)ox + 0.5f) * sx - 0.5f;
+                if (fx < 0.0f) fx = 0.0f;
+                int x0 = (int)fx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+                float lx = fx - (float)x0, hx = 1.0f - lx;
+                const float* p00 = x + (((size_t)b * h + y0) * w + x0) * c;
+                const float* p01 = x + (((size_t)b * h + y0) * w + x1) * c;
+                const float* p10 = x + (((size_t)b * h + y1) * w + x0) * c;
+                const float* p11 = x + (((size_t)b * h + y1) * w + x1) * c;
+                float* o = y + (((size_t)b * ho + oy) * wo + ox) * c;
+                for (int k = 0; k < c; ++k) {
+                    float top = hx * p00[k] + lx * p01[k];
+                    float bot = hx * p10[k] + lx * p11[k];
+                    float v = hy * top + ly * bot;
+                    o[k] = f16 ? orc_f16_round(v) : v;
+                }
+            }
+        }
+}
+
+void orc_maxpool3x3s2(const float* x, int n, int h, int w, int c, float* y) {
+    int ho = out_dim(h, 3, 2, 1), wo = out_dim(w, 3, 2, 1);
+    for (int b = 0; b < n; ++b)
+        for (int oy = 0; oy < ho; ++oy)
+            for (int ox = 0; ox < wo; ++ox) {
+                float* o = y + (((size_t)b * ho + oy) * wo + ox) * c;
+                for (int k = 0; k < c; ++k) o[k] = -INFINITY;
+                for (int r = 0; r < 3; ++r)
+                    for (int s = 0; s < 3; ++s) {
+                        int iy = oy * 2 - 1 + r, ix = ox * 2 - 1 + s;
+                        if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+                        const float* p = x + (((size_t)b * h + iy) * w + ix) * c;
+                        for (int k = 0; k < c; ++k) if (p[k] > o[k]) o[k] = p[k];
+                    }
+            }
+}
+
+/* ------------------------------------------------------------------ net */
+static tensor* new_t(orc_net* net, const char* name, int n, int h, int w, int c) {
+    if (net->nt >= MAX_T) { fprintf(stderr, "oracle: tensor table full\n"); abort(); }
+    tensor* t = &net->t[net->nt++];
+    snprintf(t->name, sizeof t->name, "%s", name);
+    t->n = n; t->h = h; t->w = w; t->c = c;
+    t->d = (float*)malloc((size_t)n * h * w * c * sizeof(float));
+    return t;
+}
+
+static void clear_t(orc_net* net) {
+    for (int i = 0; i < net->nt; ++i) free(net->t[i].d);
+    net->nt = 0;
+}
+
+static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x, int stride, int pad,
+                        const tensor* res, int act) {
+    const convw* cw = &net->convs[(*ci)++];
+    if (cw->cin != x->c) { fprintf(stderr, "oracle: conv %s cin %d vs %d\n", name, cw->cin, x->c); abort(); }
+    int ho = out_dim(x->h, cw->kh, stride, pad), wo = out_dim(x->w, cw->kw, stride, pad);
+    tensor* y = new_t(net, name, x->n, ho, wo, cw->cout);
+    conv_core(x->d, x->n, x->h, x->w, x->c, cw->wt, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
+              res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo);
+    return y;
+}
+
+static void level_dims(int S, int lh[5]) {
+    int h = out_dim(S, 7, 2, 3);   /* stem */
+    h = out_dim(h, 3, 2, 1);       /* pool */
+    h = out_dim(h, 3, 2, 1);       /* layer2 -> C3 */
+    lh[0] = h;
+    for (int i = 1; i < 5; ++i) { h = out_dim(h, 3, 2, 1); lh[i] = h; }
+}
+
+orc_net* orc_net_create(const orc_net_cfg* cfg, const void* blob, size_t nbytes) {
+    if (nbytes != orc_weights_nbytes(cfg)) return NULL;
+    const uint8_t* p = (const uint8_t*)blob;
+    if (memcmp(p, "YHW1", 4) != 0) return NULL;
+    orc_net* net = (orc_net*)calloc(1, sizeof(orc_net));
+    net->cfg = *cfg;
+    net->nconv = conv_table(cfg, NULL);
+    convspec* s = (convspec*)malloc((size_t)net->nconv * sizeof(convspec));
+    conv_table(cfg, s);
+    net->convs = (convw*)calloc((size_t)net->nconv, sizeof(convw));
+    p += 16;
+    for (int i = 0; i < net->nconv; ++i) {
+        uint32_t rec[4];
+        memcpy(rec, p, 16);
+        p += 16;
+        if ((int)rec[0] != s[i].cout || (int)rec[1] != s[i].cin || (int)rec[2] != s[i].k) { free(s); return NULL; }
+        convw* cw = &net->convs[i];
+        cw->cout = s[i].cout; cw->cin = s[i].cin; cw->kh = cw->kw = s[i].k;
+        size_t K = (size_t)cw->kh * cw->kw * cw->cin;
+        cw->wt = (float*)malloc(K * cw->cout * sizeof(float));
+        const uint16_t* w = (const uint16_t*)p;
+        for (int o = 0; o < cw->cout; ++o)
+            for (size_t k = 0; k < K; ++k) cw->wt[k * cw->cout + o] = orc_f16_bits_to_f32(w[(size_t)o * K + k]);
+        p += pad16(K * cw->cout * 2);
+        cw->bias = (float*)malloc((size_t)cw->cout * sizeof(float));
+        memcpy(cw->bias, p, (size_t)cw->cout * 4);
+        p += pad16((size_t)cw->cout * 4);
+    }
+    free(s);
+    /* geometry + priors (square anchors, aspect ratios 1, 1/2, 2) */
+    int S = cfg->input_size;
+    level_dims(S, net->lvl_h);
+    net->P = 0;
+    for (int l = 0; l < 5; ++l) { net->lvl_w[l] = net->lvl_h[l]; net->P += net->lvl_h[l] * net->lvl_w[l] * 3; }
+    net->hp = net->wp = net->lvl_h[0] * 2;
+    net->priors = (float*)malloc((size_t)net->P * 4 * sizeof(float));
+    static const float ars[3] = { 1.0f, 0.5f, 2.0f };
+    float* q = net->priors;
+    for (int l = 0; l < 5; ++l) {
+        float scale = (float)(24 << l) * (float)S / 550.0f;
+        int hh = net->lvl_h[l], ww = net->lvl_w[l];
+        for (int j = 0; j < hh; ++j)
+            for (int i = 0; i < ww; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    float wv = scale * sqrtf(ars[a]) / (float)S;
+                    q[0] = ((float)i + 0.5f) / (float)ww;
+                    q[1] = ((float)j + 0.5f) / (float)hh;
+                    q[2] = wv;
+                    q[3] = wv; /* use_square_anchors */
+                    q += 4;
+                }
+    }
+    return net;
+}
+
+void orc_net_destroy(orc_net* net) {
+    if (!net) return;
+    clear_t(net);
+    for (int i = 0; i < net->nconv; ++i) { free(net->convs[i].wt); free(net->convs[i].bias); }
+    free(net->convs);
+    free(net->priors);
+    free(net);
+}
+
+int orc_net_num_priors(const orc_net* net) { return net->P; }
+void orc_net_proto_dims(const orc_net* net, int* hp, int* wp) { *hp = net->hp; *wp = net->wp; }
+void orc_net_priors(const orc_net* net, float* out) { memcpy(out, net->priors, (size_t)net->P * 16); }
+
+double orc_net_flops_per_frame(const orc_net* net) {
+    /* recomputed geometrically, independent of a forward */
+    const orc_net_cfg* cfg = &net->cfg;
+    int S = cfg->input_size;
+    double f = 0;
+    int h = out_dim(S, 7, 2, 3);
+    f += 2.0 * h * h * 64 * 49 * 3;
+    h = out_dim(h, 3, 2, 1);
+    int inc = 64;
+    for (int L = 0; L < 4; ++L) {
+        int planes = 64 << L;
+        for (int b = 0; b < blocks_of(cfg->backbone, L); ++b) {
+            int stride = (b == 0 && L > 0) ? 2 : 1;
+            int ho = out_dim(h, 3, stride, 1);
+            f += 2.0 * h * h * planes * inc;
+            f += 2.0 * ho * ho * planes * 9.0 * planes;
+            f += 2.0 * ho * ho * planes * 4.0 * planes;
+            if (b == 0) f += 2.0 * ho * ho * planes * 4.0 * inc;
+            inc = planes * 4;
+            h = ho;
+        }
+    }
+    const int* lh = net->lvl_h;
+    f += 2.0 * lh[2] * lh[2] * 256 * 2048.0 + 2.0 * lh[1] * lh[1] * 256 * 1024.0 + 2.0 * lh[0] * lh[0] * 256 * 512.0;
+    for (int l = 0; l < 3; ++l) f += 2.0 * lh[l] * lh[l] * 256 * 2304.0;
+    f += 2.0 * lh[3] * lh[3] * 256 * 2304.0 + 2.0 * lh[4] * lh[4] * 256 * 2304.0;
+    f += 3 * 2.0 * lh[0] * lh[0] * 256 * 2304.0;
+    f += 2.0 * net->hp * net->hp * 256 * 2304.0 + 2.0 * net->hp * net->hp * 32 * 256.0;
+    for (int l = 0; l < 5; ++l)
+        f += 2.0 * lh[l] * lh[l] * 2304.0 * (256 + 12 + 3 * cfg->num_classes + 96);
+    return f;
+}
+
+static const float MEANS[3] = { 123.68f, 116.78f, 103.94f };
+static const float STDS[3] = { 58.40f, 57.12f, 57.38f };
+
+int orc_net_forward(orc_net* net, const uint8_t* rgb, int n, int f16_storage, int nthreads,
+                    float* loc, float* conf, float* mask, float* proto) {
+    clear_t(net);
+    net->f16 = f16_storage;
+    net->nthreads = nthreads;
+    int S = net->cfg.input_size, C = net->cfg.num_classes, ci = 0;
+    char nm[24];
+    tensor* in = new_t(net, "input", n, S, S, 3);
+    for (size_t i = 0; i < (size_t)n * S * S; ++i)
+        for (int c = 0; c < 3; ++c) {
+            float v = ((float)rgb[i * 3 + c] - MEANS[c]) / STDS[c];
+            in->d[i * 3 + c] = f16_storage ? orc_f16_round(v) : v;
+        }
+    tensor* x = run_conv(net, &ci, "stem", in, 2, 3, NULL, 1);
+    tensor* pool = new_t(net, "pool", n, out_dim(x->h, 3, 2, 1), out_dim(x->w, 3, 2, 1), 64);
+    orc_maxpool3x3s2(x->d, n, x->h, x->w, 64, pool->d);
+    x = pool;
+    tensor* cfeat[4];
+    for (int L = 0; L < 4; ++L) {
+        for (int b = 0; b < blocks_of(net->cfg.backbone, L); ++b) {
+            int stride = (b == 0 && L > 0) ? 2 : 1;
+            snprintf(nm, sizeof nm, "l%db%d_a", L + 1, b);
+            tensor* a = run_conv(net, &ci, nm, x, 1, 0, NULL, 1);
+            snprintf(nm, sizeof nm, "l%db%d_b", L + 1, b);
+            tensor* bt = run_conv(net, &ci, nm, a, stride, 1, NULL, 1);
+            /* canonical order: conv3 then downsample; evaluate downsample first, it is conv3's residual */
+            int ci3 = ci++;
+            const tensor* res = x;
+            if (b == 0) {
+                snprintf(nm, sizeof nm, "l%db%d_d", L + 1, b);
+                res = run_conv(net, &ci, nm, x, stride, 0, NULL, 0);
+            }
+            snprintf(nm, sizeof nm, "l%db%d", L + 1, b);
+            x = run_conv(net, &ci3, nm, bt, 1, 0, res, 1);
+        }
+        cfeat[L] = x;
+        snprintf(nm, sizeof nm, "c%d", L + 2);
+        snprintf(x->name, sizeof x->name, "%s", nm);
+    }
+    /* FPN top-down */
+    tensor* lat5 = run_conv(net, &ci, "lat5", cfeat[3], 1, 0, NULL, 0);
+    tensor* up5 = new_t(net, "up5", n, cfeat[2]->h, cfeat[2]->w, 256);
+    orc_bilinear(lat5->d, n, lat5->h, lat5->w, 256, up5->h, up5->w, f16_storage, up5->d);
+    tensor* lat4 = run_conv(net, &ci, "lat4", cfeat[2], 1, 0, up5, 0);
+    tensor* up4 = new_t(net, "up4", n, cfeat[1]->h, cfeat[1]->w, 256);
+    orc_bilinear(lat4->d, n, lat4->h, lat4->w, 256, up4->h, up4->w, f16_storage, up4->d);
+    tensor* lat3 = run_conv(net, &ci, "lat3", cfeat[1], 1, 0, up4, 0);
+    tensor* P[5];
+    P[2] = run_conv(net, &ci, "p5", lat5, 1, 1, NULL, 1);
+    P[1] = run_conv(net, &ci, "p4", lat4, 1, 1, NULL, 1);
+    P[0] = run_conv(net, &ci, "p3", lat3, 1, 1, NULL, 1);
+    P[3] = run_conv(net, &ci, "p6", P[2], 2, 1, NULL, 0);
+    P[4] = run_conv(net, &ci, "p7", P[3], 2, 1, NULL, 0);
+    /* protonet */
+    tensor* q = P[0];
+    for (int i = 0; i < 3; ++i) { snprintf(nm, sizeof nm, "proto%d", i); q = run_conv(net, &ci, nm, q, 1, 1, NULL, 1); }
+    tensor* qu = new_t(net, "proto_up", n, q->h * 2, q->w * 2, 256);
+    orc_bilinear(q->d, n, q->h, q->w, 256, qu->h, qu->w, f16_storage, qu->d);
+    q = run_conv(net, &ci, "proto3", qu, 1, 1, NULL, 1);
+    tensor* pr = run_conv(net, &ci, "proto", q, 1, 0, NULL, 1);
+    if (proto) memcpy(proto, pr->d, (size_t)n * pr->h * pr->w * 32 * sizeof(float));
+    /* shared prediction head over the five levels */
+    int ci_head = ci;
+    size_t off = 0;
+    for (int l = 0; l < 5; ++l) {
+        ci = ci_head;
+        snprintf(nm, sizeof nm, "head_t%d", l);
+        tensor* t = run_conv(net, &ci, nm, P[l], 1, 1, NULL, 1);
+        snprintf(nm, sizeof nm, "head_box%d", l);
+        tensor* bx = run_conv(net, &ci, nm, t, 1, 1, NULL, 0);
+        snprintf(nm, sizeof nm, "head_conf%d", l);
+        tensor* cf = run_conv(net, &ci, nm, t, 1, 1, NULL, 0);
+        snprintf(nm, sizeof nm, "head_mask%d", l);
+        tensor* mk = run_conv(net, &ci, nm, t, 1, 1, NULL, 2);
+        size_t cells = (size_t)t->h * t->w;
+        for (int b = 0; b < n; ++b) {
+            if (loc) memcpy(loc + ((size_t)b * net->P + off) * 4, bx->d + (size_t)b * cells * 12, cells * 12 * sizeof(float));
+            if (conf) memcpy(conf + ((size_t)b * net->P + off) * C, cf->d + (size_t)b * cells * 3 * C, cells * 3 * C * sizeof(float));
+            if (mask) memcpy(mask + ((size_t)b * net->P + off) * 32, mk->d + (size_t)b * cells * 96, cells * 96 * sizeof(float));
+        }
+        off += cells * 3;
+    }
+    return 0;
+}
+
+long orc_net_get(const orc_net* net, const char* name, float* out, size_t cap, int dims[4]) {
+    for (int i = 0; i < net->nt; ++i)
+        if (strcmp(net->t[i].name, name) == 0) {
+            const tensor* t = &net->t[i];
+            size_t ne = (size_t)t->n * t->h * t->w * t->c;
+            if (dims) { dims[0] = t->n; dims[1] = t->h; dims[2] = t->w; dims[3] = t->c; }
+            if (out) { if (ne > cap) return -1; memcpy(out, t->d, ne * sizeof(float)); }
+            return (long)ne;
+        }
+    return -1;
+}
