@@ -253,7 +253,9 @@ void orc_conv2d(const float* x, int n, int h, int w, int cin, const float* wk, c
     free(wt);
 }
 
-/* Bilinear, align_corners=false (half-pixel centres), scale = in/out, source clamped at 0. */
+/* Bilinear, align_corners=false (half-pixel centres), scale = in/out, source clamped at 0.
+ * fp-contract off: each operator below is one IEEE operation. */
+__attribute__((optimize("fp-contract=off")))
 void orc_bilinear(const float* x, int n, int h, int w, int c, int ho, int wo, int f16, float* y) {
     float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
     for (int b = 0; b < n; ++b)

@@ -1,0 +1,251 @@
+// conv_igemm.hip — NHWC f16 convolution as an implicit GEMM on CDNA4 MFMA (gfx950).
+//
+// Replaces, for the YOLACT path, the CONV_2D / ADD / PAD / RELU / TANH ops that the reference
+// executes inside interpreter.invoke() (/root/reference/src/yolact.rs:163; op histogram
+// data/FRC_model_edgetpu.log:7-19): bias, residual add, ReLU and tanh are fused in the epilogue,
+// zero padding is the buffer-descriptor bounds check of the activation loads.
+//
+//   D[ch][m] = sum_k Wt[ch][k] * X[m][k]     (weights are the MFMA A operand, activations B)
+//
+// Work decomposition: one 256-thread workgroup (4 waves, one per SIMD) owns a TCH x TM output
+// tile; each wave owns (TCH/WCH) x (TM/WM) of it as 32x32 v_mfma_f32_32x32x16_f16 tiles with f32
+// accumulators. K advances 64 at a time (one 128-byte row segment per tile row): global ->
+// registers (16 B per lane, 8 lanes per 128-B line) -> LDS, double buffered, one barrier per step,
+// the loads of step k+1 issued before the MFMAs of step k (register staging, T14 order).
+// LDS rows are 128 B; 16-byte chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)), which makes
+// both the ds_write_b128 staging stores and the ds_read_b128 fragment reads conflict free
+// (bank row = 256 B = two LDS rows).
+// Epilogue: accumulators -> LDS as f32 [m][ch] (lane holds 4 consecutive channels per register
+// quad), then whole 16-byte f16 channel groups are written with coalesced row stores.
+#include "yh_internal.h"
+
+namespace yh {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int A, int B>
+struct cmax { static constexpr int v = A > B ? A : B; };
+
+template <int TCH, int TM, int WCH, int WM, bool SMALLC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
+    constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
+    constexpr int TC = WTC / 32, TMT = WTM / 32;   // MFMA tiles per wave
+    constexpr int XL = TM / 32, WL = TCH / 32;     // 16-byte staging loads per thread
+    constexpr int AB_BYTES = (TCH + TM) * 128;
+    constexpr int ES = TCH + 4;                    // epilogue row stride in floats
+    constexpr int LDS_BYTES = cmax<2 * AB_BYTES, TM * ES * 4>::v;
+    static_assert(WCH * WM == 4 && WTC % 32 == 0 && WTM % 32 == 0, "4 waves, 32x32 tiles");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    // XCD-aware bijective remap: consecutive work ids (which share activation rows / weight
+    // panels) land on one XCD's L2 instead of being dealt round-robin over the eight.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ch_tile = wg % p.n_ch_tiles, m_tile = wg / p.n_ch_tiles;
+
+    const int tid = threadIdx.x, chunk = tid & 7, rb = tid >> 3;
+    const int PQ = p.P * p.Q;
+
+    // ---- per-thread staging rows of the activation tile
+    int xbase[XL], xih[XL], xiw[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int m = m_tile * TM + rb + 32 * i;
+        if (m < p.M) {
+            const int n = m / PQ, rem = m - n * PQ;
+            const int op = rem / p.Q, oq = rem - op * p.Q;
+            xih[i] = op * p.stride - p.pad;
+            xiw[i] = oq * p.stride - p.pad;
+            xbase[i] = (int)(n * p.x_img_stride) + (xih[i] * p.W + xiw[i]) * p.C + (SMALLC ? 0 : chunk * 8);
+        } else {
+            xih[i] = -(1 << 24);
+            xiw[i] = 0;
+            xbase[i] = 0;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const half_t* wptr = p.w + (size_t)(ch_tile * TCH + rb) * p.ldw + chunk * 8;
+
+    // position of the NEXT tile to load along K
+    int kr = 0, ks = 0, kc = 0, kt_load = 0;
+    u32x4 xr[XL], wr[WL];
+
+    auto load_tile = [&]() {
+        int r, s, rs_off;
+        if (SMALLC) {
+            const int2 tap = p.rs_table[kt_load * 8 + chunk];
+            r = tap.x; s = tap.y;
+            rs_off = (r * p.W + s) * 8;
+        } else {
+            r = kr; s = ks;
+            rs_off = (kr * p.W + ks) * p.C + kc;
+        }
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const bool ok = (unsigned)(xih[i] + r) < (unsigned)p.H && (unsigned)(xiw[i] + s) < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)(xbase[i] + rs_off) * 2u : p.x_bytes;
+            xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            wr[i] = *(const u32x4*)(wptr + (size_t)(32 * i) * p.ldw + kt_load * 64);
+        ++kt_load;
+        if (!SMALLC) {
+            kc += 64;
+            if (kc >= p.C) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+        }
+    };
+    // swizzled LDS byte offset of (row rb + 32 i, chunk): the XOR term is constant per thread
+    const int st_off = rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
+    auto store_tile = [&](int buf) {
+        char* base = lds + buf * AB_BYTES;
+#pragma unroll
+        for (int i = 0; i < WL; ++i) *(u32x4*)(base + st_off + i * 4096) = wr[i];
+#pragma unroll
+        for (int i = 0; i < XL; ++i) *(u32x4*)(base + TCH * 128 + st_off + i * 4096) = xr[i];
+    };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wc = wid / WM, wm = wid % WM;
+    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
+    const int a_row = (wc * WTC + l31) * 128, b_row = TCH * 128 + (wm * WTM + l31) * 128;
+
+    f32x16 acc[TC][TMT];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TMT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < p.ksteps; ++kt) {
+        const bool more = kt + 1 < p.ksteps;
+        if (more) load_tile();
+        const char* base = lds + cur * AB_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((2 * kk + lh) ^ swz) << 4;
+            half8 a[TC], b[TMT];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base + a_row + i * 4096 + co);
+#pragma unroll
+            for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base + b_row + j * 4096 + co);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TMT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: accumulators -> LDS f32 [m][ch]
+    float* E = (float*)lds;
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TMT; ++j) {
+            const int m_l = wm * WTM + j * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch_l = wc * WTC + i * 32 + 8 * g + 4 * lh;
+                f32x4 v = { acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3] };
+                *(f32x4*)(E + m_l * ES + ch_l) = v;
+            }
+        }
+    __syncthreads();
+
+    constexpr int TPR = TCH / 8, RPP = 256 / TPR;
+    const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
+    const int ch = ch_tile * TCH + ch_l;
+    if (ch >= p.cout8) return;
+    float bias8[8];
+    {
+        const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+#pragma unroll 2
+    for (int pass = 0; pass < TM / RPP; ++pass) {
+        const int m_l = pass * RPP + rr, m = m_tile * TM + m_l;
+        if (m >= p.M) break;
+        const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+        long long yo, ro;
+        if (p.y_dense) {
+            yo = (long long)m * p.ldy + ch;
+            ro = (long long)m * p.ldres + ch;
+        } else {
+            const int n = m / PQ, rem = m - n * PQ;
+            yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
+            ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
+        }
+        if (p.res) {
+            const half8 rv = *(const half8*)(p.res + ro);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (ch + 8 > p.tanh_from) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        *(half8*)(p.y + yo) = o;
+    }
+}
+
+int conv_tile_ch(ConvTile t) {
+    switch (t) { case TILE_128x128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+                 case TILE_32x256: return 32; case TILE_256x128: return 256; }
+    return 0;
+}
+int conv_tile_m(ConvTile t) {
+    switch (t) { case TILE_128x128: case TILE_256x128: return 128; default: return 256; }
+}
+const char* conv_tile_symbol(ConvTile t) {
+    switch (t) {
+        case TILE_128x128: return "conv_igemm_f16<128,128,2,2,0>";
+        case TILE_64x256: return "conv_igemm_f16<64,256,1,4,0>";
+        case TILE_32x256: return "conv_igemm_f16<32,256,1,4,0>";
+        case TILE_64x256_SMALLC: return "conv_igemm_f16<64,256,1,4,1>";
+        case TILE_256x128: return "conv_igemm_f16<256,128,4,1,0>";
+    }
+    return "?";
+}
+
+hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
+    const int tm = conv_tile_m(tile);
+    const int n_m_tiles = (p.M + tm - 1) / tm;
+    const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles)), block(256);
+    switch (tile) {
+        case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false>), grid, block, 0, stream, p); break;
+        case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false>), grid, block, 0, stream, p); break;
+        case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false>), grid, block, 0, stream, p); break;
+        case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true>), grid, block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace yh

@@ -1,0 +1,157 @@
+// elementwise.hip — HBM-bound gather / element-wise kernels of the YOLACT forward.
+// Compiled with -ffp-contract=off: every float expression is one IEEE op per operator, in the
+// order DESIGN.md §Spec fixes, so results are bit-identical to the oracle on equal inputs.
+//
+// These replace, for the YOLACT path, the QUANTIZE (input), RESIZE_BILINEAR and max-pool style
+// ops inside interpreter.invoke() (/root/reference/src/yolact.rs:163;
+// data/FRC_model_edgetpu.log:7-19). All loads/stores are 16 bytes per lane (8 f16 channels),
+// consecutive lanes on consecutive channel groups of one pixel: fully coalesced NHWC rows.
+#include "yh_internal.h"
+
+namespace yh {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// u8 RGB -> f16 (v - mean)/std, channels padded 3 -> 8 with zeros (stem runs in small-C mode).
+__global__ __launch_bounds__(256) void preprocess_rgb8_f16(const uint8_t* __restrict__ rgb,
+                                                           half_t* __restrict__ out, long long npix) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
+    half8 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (half_t)(((float)rgb[i * 3 + c] - mean[c]) / sd[c]);
+#pragma unroll
+    for (int c = 3; c < 8; ++c) o[c] = (half_t)0.0f;
+    *(half8*)(out + i * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                        int n, int h, int w, int c8, int ho, int wo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)n * ho * wo * c8;
+    if (t >= total) return;
+    const int cg = (int)(t % c8);
+    long long r = t / c8;
+    const int ox = (int)(r % wo); r /= wo;
+    const int oy = (int)(r % ho);
+    const int b = (int)(r / ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)w) continue;
+            const half8 v = *(const half8*)(x + (((long long)b * h + iy) * w + ix) * c8 * 8 + cg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = (float)v[e] > m[e] ? (float)v[e] : m[e];
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+    *(half8*)(y + t * 8) = o;
+}
+
+// Bilinear resize, align_corners = false: src = (dst + 0.5) * in/out - 0.5 clamped at 0.
+__global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                    int n, int h, int w, int c8, int ho, int wo,
+                                                    long long x_img_stride, long long y_img_stride) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)n * ho * wo * c8;
+    if (t >= total) return;
+    const int cg = (int)(t % c8);
+    long long r = t / c8;
+    const int ox = (int)(r % wo); r /= wo;
+    const int oy = (int)(r % ho);
+    const int b = (int)(r / ho);
+    const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+    float fy = ((float)oy + 0.5f) * sy - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    float fx = ((float)ox + 0.5f) * sx - 0.5f;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    const int x0 = (int)fx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+    const half_t* xb = x + b * x_img_stride + cg * 8;
+    const int c = c8 * 8;
+    const half8 p00 = *(const half8*)(xb + ((long long)y0 * w + x0) * c);
+    const half8 p01 = *(const half8*)(xb + ((long long)y0 * w + x1) * c);
+    const half8 p10 = *(const half8*)(xb + ((long long)y1 * w + x0) * c);
+    const half8 p11 = *(const half8*)(xb + ((long long)y1 * w + x1) * c);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float top = hx * (float)p00[e] + lx * (float)p01[e];
+        const float bot = hx * (float)p10[e] + lx * (float)p11[e];
+        o[e] = (half_t)(hy * top + ly * bot);
+    }
+    *(half8*)(y + b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8) = o;
+}
+
+// Output reads (not on the hot path): split the fused head rows into loc / conf / mask as f32.
+__global__ __launch_bounds__(256) void split_heads_f32(const half_t* __restrict__ heads, long long rows, int ldh,
+                                                       int C, float* loc, float* conf, float* mask) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per = 12 + 3 * C + 96;
+    if (t >= rows * per) return;
+    const long long row = t / per;
+    const int j = (int)(t % per);
+    const float v = (float)heads[row * ldh + j];
+    if (j < 12) { if (loc) loc[row * 12 + j] = v; }
+    else if (j < 12 + 3 * C) { if (conf) conf[row * 3 * C + (j - 12)] = v; }
+    else if (mask) mask[row * 96 + (j - 12 - 3 * C)] = v;
+}
+
+__global__ __launch_bounds__(256) void f16_to_f32(const half_t* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) y[t] = (float)x[t];
+}
+
+// Output 4 ("cells"): class logits of anchor 0 on the stride-8 level, [n][cells_l0][C] f32.
+__global__ __launch_bounds__(256) void cells_f32(const half_t* __restrict__ heads, int n, int cells_img, int cells_l0,
+                                                 int ldh, int C, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * cells_l0 * C) return;
+    const int c = (int)(t % C);
+    const long long r = t / C;
+    const int cell = (int)(r % cells_l0), b = (int)(r / cells_l0);
+    out[t] = (float)heads[((long long)b * cells_img + cell) * ldh + 12 + c];
+}
+
+static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t launch_preprocess(const uint8_t* rgb, half_t* out8, long long npix, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_rgb8_f16, dim3(nblk(npix)), dim3(256), 0, s, rgb, out8, npix);
+    return hipGetLastError();
+}
+hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s) {
+    hipLaunchKernelGGL(maxpool3x3s2_f16, dim3(nblk((long long)n * ho * wo * (c / 8))), dim3(256), 0, s, x, y, n, h, w, c / 8, ho, wo);
+    return hipGetLastError();
+}
+hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
+                           long long xs, long long ys, hipStream_t s) {
+    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)n * ho * wo * (c / 8))), dim3(256), 0, s, x, y, n, h, w, c / 8, ho, wo, xs, ys);
+    return hipGetLastError();
+}
+hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc, float* conf,
+                              float* mask, hipStream_t s) {
+    const long long rows = (long long)n * cells;
+    hipLaunchKernelGGL(split_heads_f32, dim3(nblk(rows * (12 + 3 * C + 96))), dim3(256), 0, s, heads, rows, ldh, C, loc, conf, mask);
+    return hipGetLastError();
+}
+hipError_t launch_f16_to_f32(const half_t* x, float* y, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(f16_to_f32, dim3(nblk(n)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_cells_f32(const half_t* heads, int n, int cells_img, int cells_l0, int ldh, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(cells_f32, dim3(nblk((long long)n * cells_l0 * C)), dim3(256), 0, s, heads, n, cells_img, cells_l0, ldh, C, out);
+    return hipGetLastError();
+}
+
+}  // namespace yh

@@ -1,0 +1,1118 @@
+// engine.hip — the YOLACT engine behind the C ABI of include/yolact_hip.h.
+//
+// Stands in for the reference's `struct Yolact` + tflite Interpreter (/root/reference/src/
+// yolact.rs:13-37): builds the layer table, owns one static arena sized for
+// max_batch (every layer output stays resident: 288 GB of HBM make aliasing unnecessary and every
+// intermediate inspectable), a private stream, the repacked weight panels, and the op list that
+// yh_invoke / yh_evaluate replay (optionally as a captured hipGraph).
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "yh_internal.h"
+
+using namespace yh;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ConvDesc {          // one canonical conv of the blob
+    int cout, cin, k;
+    float gain;
+    int is_conf;
+    size_t blob_w_off, blob_b_off;  // byte offsets in the canonical blob
+};
+
+struct Panel {             // device-side repacked weights of one launched conv
+    half_t* w = nullptr;   // [coutPad][Kpad]
+    float* bias = nullptr; // [coutPad]
+    int2* rs_table = nullptr;
+    int cout = 0, coutPad = 0, Kpad = 0, cin_store = 0, k = 0;
+    ConvTile tile = TILE_128x128;
+    std::vector<int> src;  // canonical conv indices concatenated along cout
+};
+
+struct Buf {               // dense NHWC f16 tensor [max_batch][h][w][c] or a slice of one
+    half_t* d = nullptr;
+    int h = 0, w = 0, c = 0;       // c = row stride in elements
+    long long img_stride = 0;      // elements per image
+};
+
+enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_BILINEAR };
+
+struct Op {
+    OpKind kind;
+    std::string name;      // layer name (matches the oracle's intermediate names)
+    std::string label;     // "kernel_symbol:layer"
+    Buf in, out, res;
+    bool has_res = false;
+    int panel = -1;
+    int stride = 1, pad = 0, act = 0, tanh_from = INT_MAX;
+    int P = 0, Q = 0;      // output spatial
+    double flops_per_img = 0, bytes_per_img = 0, bytes_fixed = 0;
+};
+
+size_t pad16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+int out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+
+uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+float unit_rand(uint64_t seed, uint64_t conv, uint64_t stream, uint64_t e) {
+    const uint64_t u = splitmix(splitmix(seed + conv * 1000003ull + stream) + e);
+    return ((float)(uint32_t)(u >> 40) - 8388608.0f) * (1.0f / 8388608.0f);
+}
+uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
+    const _Float16 h = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+
+}  // namespace
+
+struct yh_engine {
+    yh_config cfg;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    int S = 0, C = 0, ldh = 0;
+    int lvl[5] = { 0, 0, 0, 0, 0 }, lvl_off[5] = { 0, 0, 0, 0, 0 };
+    int cells = 0, P = 0, hp = 0, wp = 0;
+    double flops_per_frame = 0;
+
+    std::vector<ConvDesc> convs;
+    size_t blob_bytes = 0;
+    std::vector<Panel> panels;
+    std::vector<Op> ops;
+    std::vector<void*> allocs;
+    std::map<std::string, Buf> named;
+
+    uint8_t* in_u8 = nullptr;
+    Buf in_f16, pyr, pyr_t, heads, proto;
+    float* priors_dev = nullptr;
+    std::vector<float> priors_host;
+
+    // tail workspaces / outputs
+    DetectParams det{};
+    // compat-path scratch
+    uint32_t* frame_dev = nullptr;
+    float* rs_tmp = nullptr;
+    float* cells_dev = nullptr;
+    uint32_t* codes_dev = nullptr;
+    uint32_t* stitch_dev = nullptr;
+    int* diverged_dev = nullptr;
+    size_t frame_cap = 0, rs_tmp_cap = 0;
+    // output staging
+    float* out_f32 = nullptr;
+    size_t out_f32_cap = 0;
+
+    bool weights_loaded = false;
+    int cur_n = 0;
+    std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+#define HIPCHK(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return (h)->fail(YH_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+namespace {
+
+int dev_alloc(yh_engine* h, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return h->fail(YH_ENOMEM, std::string("hipMalloc ") + std::to_string(bytes) + ": " + hipGetErrorString(e));
+    h->allocs.push_back(*p);
+    return YH_OK;
+}
+
+int new_buf(yh_engine* h, const char* name, int hh, int ww, int c, Buf* out) {
+    Buf b;
+    b.h = hh; b.w = ww; b.c = c;
+    b.img_stride = (long long)hh * ww * c;
+    void* p = nullptr;
+    int rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * b.img_stride * 2);
+    if (rc) return rc;
+    b.d = (half_t*)p;
+    if (name) h->named[name] = b;
+    *out = b;
+    return YH_OK;
+}
+
+int blocks_of(int backbone, int layer) {
+    static const int r50[4] = { 3, 4, 6, 3 }, r101[4] = { 3, 4, 23, 3 };
+    return backbone == YH_BACKBONE_R101 ? r101[layer] : r50[layer];
+}
+
+// Canonical conv table (DESIGN.md §Weight blob) — order defines the blob layout.
+void build_conv_table(yh_engine* h) {
+    auto add = [&](int co, int ci, int k, float g, int conf) {
+        ConvDesc d; d.cout = co; d.cin = ci; d.k = k; d.gain = g; d.is_conf = conf; d.blob_w_off = d.blob_b_off = 0;
+        h->convs.push_back(d);
+    };
+    add(64, 3, 7, 1.0f, 0);
+    int inc = 64;
+    for (int L = 0; L < 4; ++L) {
+        const int planes = 64 << L;
+        for (int b = 0; b < blocks_of(h->cfg.backbone, L); ++b) {
+            add(planes, inc, 1, 1.0f, 0);
+            add(planes, planes, 3, 1.0f, 0);
+            add(planes * 4, planes, 1, 0.3f, 0);
+            if (b == 0) add(planes * 4, inc, 1, 1.0f, 0);
+            inc = planes * 4;
+        }
+    }
+    add(256, 2048, 1, 0.2f, 0); add(256, 1024, 1, 0.2f, 0); add(256, 512, 1, 0.2f, 0);
+    for (int i = 0; i < 3; ++i) add(256, 256, 3, 0.7f, 0);
+    for (int i = 0; i < 2; ++i) add(256, 256, 3, 1.0f, 0);
+    for (int i = 0; i < 4; ++i) add(256, 256, 3, 1.0f, 0);
+    add(32, 256, 1, 1.0f, 0);
+    add(256, 256, 3, 1.0f, 0);
+    add(12, 256, 3, 0.1f, 0);
+    add(3 * h->C, 256, 3, 0.7f, 1);
+    add(96, 256, 3, 0.5f, 0);
+    size_t off = 16;
+    for (auto& d : h->convs) {
+        off += 16;
+        d.blob_w_off = off;
+        off += pad16((size_t)d.cout * d.k * d.k * d.cin * 2);
+        d.blob_b_off = off;
+        off += pad16((size_t)d.cout * 4);
+    }
+    h->blob_bytes = off;
+}
+
+int add_panel(yh_engine* h, std::vector<int> src) {
+    Panel p;
+    p.src = src;
+    const ConvDesc& d0 = h->convs[src[0]];
+    p.k = d0.k;
+    p.cin_store = d0.cin == 3 ? 8 : d0.cin;
+    int cout = 0;
+    for (int s : src) cout += h->convs[s].cout;
+    p.cout = cout;
+    if (d0.cin == 3) p.tile = TILE_64x256_SMALLC;
+    else if (cout <= 32) p.tile = TILE_32x256;
+    else if (cout <= 64) p.tile = TILE_64x256;
+    else p.tile = TILE_128x128;
+    p.coutPad = round_up(cout, conv_tile_ch(p.tile));
+    p.Kpad = d0.cin == 3 ? round_up(d0.k * d0.k, 8) * 8 : d0.k * d0.k * d0.cin;
+    h->panels.push_back(p);
+    return (int)h->panels.size() - 1;
+}
+
+Op conv_op(yh_engine* h, const char* name, int panel, const Buf& in, const Buf& out, int stride, int pad,
+           int act, const Buf* res) {
+    Op o;
+    o.kind = OP_CONV;
+    o.name = name;
+    o.panel = panel;
+    o.in = in; o.out = out;
+    if (res) { o.res = *res; o.has_res = true; }
+    o.stride = stride; o.pad = pad; o.act = act;
+    const Panel& p = h->panels[panel];
+    o.P = out_dim(in.h, p.k, stride, pad);
+    o.Q = out_dim(in.w, p.k, stride, pad);
+    const ConvDesc& d0 = h->convs[p.src[0]];
+    const double K = (double)p.k * p.k * d0.cin;
+    o.flops_per_img = 2.0 * o.P * o.Q * p.cout * K;
+    o.bytes_per_img = 2.0 * ((double)in.h * in.w * d0.cin + (double)o.P * o.Q * p.cout * (res ? 2 : 1));
+    o.bytes_fixed = 2.0 * p.cout * K;
+    o.label = std::string(conv_tile_symbol(p.tile)) + ":" + name;
+    return o;
+}
+
+int build_graph_spec(yh_engine* h) {
+    const int S = h->S, N = h->cfg.max_batch;
+    (void)N;
+    int rc;
+    void* p = nullptr;
+    if ((rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * S * S * 3))) return rc;
+    h->in_u8 = (uint8_t*)p;
+    if ((rc = new_buf(h, "input", S, S, 8, &h->in_f16))) return rc;
+
+    int ci = 0;  // canonical conv cursor
+    {
+        Op o; o.kind = OP_PRE; o.name = "input"; o.label = "preprocess_rgb8_f16:input";
+        o.bytes_per_img = (double)S * S * (3 + 16);
+        h->ops.push_back(o);
+    }
+    const int H1 = out_dim(S, 7, 2, 3), H2 = out_dim(H1, 3, 2, 1);
+    Buf stem, pool;
+    if ((rc = new_buf(h, "stem", H1, H1, 64, &stem))) return rc;
+    if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
+    h->ops.push_back(conv_op(h, "stem", add_panel(h, { ci++ }), h->in_f16, stem, 2, 3, 1, nullptr));
+    {
+        Op o; o.kind = OP_POOL; o.name = "pool"; o.label = "maxpool3x3s2_f16:pool"; o.in = stem; o.out = pool;
+        o.P = H2; o.Q = H2;
+        o.bytes_per_img = 2.0 * 64 * ((double)H1 * H1 + (double)H2 * H2);
+        h->ops.push_back(o);
+    }
+    Buf x = pool, cfeat[4];
+    char nm[32];
+    for (int L = 0; L < 4; ++L) {
+        const int planes = 64 << L;
+        for (int b = 0; b < blocks_of(h->cfg.backbone, L); ++b) {
+            const int stride = (b == 0 && L > 0) ? 2 : 1;
+            const int ho = out_dim(x.h, 3, stride, 1);
+            Buf a, bt, y, dn;
+            snprintf(nm, sizeof nm, "l%db%d_a", L + 1, b);
+            if ((rc = new_buf(h, nm, x.h, x.w, planes, &a))) return rc;
+            h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), x, a, 1, 0, 1, nullptr));
+            snprintf(nm, sizeof nm, "l%db%d_b", L + 1, b);
+            if ((rc = new_buf(h, nm, ho, ho, planes, &bt))) return rc;
+            h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), a, bt, stride, 1, 1, nullptr));
+            const int ci3 = ci++;
+            Buf resb = x;
+            if (b == 0) {
+                snprintf(nm, sizeof nm, "l%db%d_d", L + 1, b);
+                if ((rc = new_buf(h, nm, ho, ho, planes * 4, &dn))) return rc;
+                h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), x, dn, stride, 0, 0, nullptr));
+                resb = dn;
+            }
+            const bool last = b == blocks_of(h->cfg.backbone, L) - 1;
+            if (last) snprintf(nm, sizeof nm, "c%d", L + 2);
+            else snprintf(nm, sizeof nm, "l%db%d", L + 1, b);
+            if ((rc = new_buf(h, nm, ho, ho, planes * 4, &y))) return rc;
+            h->ops.push_back(conv_op(h, nm, add_panel(h, { ci3 }), bt, y, 1, 0, 1, &resb));
+            x = y;
+        }
+        cfeat[L] = x;
+    }
+    // ---- FPN
+    for (int l = 0; l < 5; ++l) h->lvl[l] = l == 0 ? cfeat[1].h : out_dim(h->lvl[l - 1], 3, 2, 1);
+    if (h->lvl[1] != cfeat[2].h || h->lvl[2] != cfeat[3].h) return h->fail(YH_EINVAL, "pyramid geometry mismatch");
+    h->cells = 0;
+    for (int l = 0; l < 5; ++l) { h->lvl_off[l] = h->cells; h->cells += h->lvl[l] * h->lvl[l]; }
+    h->P = h->cells * 3;
+    h->hp = h->wp = h->lvl[0] * 2;
+    h->ldh = round_up(12 + 3 * h->C + 96, 8);
+    if ((rc = new_buf(h, "pyr", h->cells, 1, 256, &h->pyr))) return rc;
+    if ((rc = new_buf(h, "pyr_t", h->cells, 1, 256, &h->pyr_t))) return rc;
+    if ((rc = new_buf(h, "heads", h->cells, 1, h->ldh, &h->heads))) return rc;
+    auto level = [&](const Buf& base, int l) {
+        Buf b = base;
+        b.d = base.d + (long long)h->lvl_off[l] * base.c;
+        b.h = b.w = h->lvl[l];
+        return b;
+    };
+    Buf lat5, lat4, lat3, up5, up4;
+    if ((rc = new_buf(h, "lat5", cfeat[3].h, cfeat[3].w, 256, &lat5))) return rc;
+    if ((rc = new_buf(h, "up5", cfeat[2].h, cfeat[2].w, 256, &up5))) return rc;
+    if ((rc = new_buf(h, "lat4", cfeat[2].h, cfeat[2].w, 256, &lat4))) return rc;
+    if ((rc = new_buf(h, "up4", cfeat[1].h, cfeat[1].w, 256, &up4))) return rc;
+    if ((rc = new_buf(h, "lat3", cfeat[1].h, cfeat[1].w, 256, &lat3))) return rc;
+    auto bil = [&](const char* name, const Buf& in, const Buf& out) {
+        Op o; o.kind = OP_BILINEAR; o.name = name; o.label = std::string("bilinear_f16:") + name; o.in = in; o.out = out;
+        o.P = out.h; o.Q = out.w;
+        o.bytes_per_img = 2.0 * in.c * ((double)in.h * in.w + (double)out.h * out.w);
+        h->ops.push_back(o);
+    };
+    h->ops.push_back(conv_op(h, "lat5", add_panel(h, { ci++ }), cfeat[3], lat5, 1, 0, 0, nullptr));
+    bil("up5", lat5, up5);
+    h->ops.push_back(conv_op(h, "lat4", add_panel(h, { ci++ }), cfeat[2], lat4, 1, 0, 0, &up5));
+    bil("up4", lat4, up4);
+    h->ops.push_back(conv_op(h, "lat3", add_panel(h, { ci++ }), cfeat[1], lat3, 1, 0, 0, &up4));
+    h->ops.push_back(conv_op(h, "p5", add_panel(h, { ci++ }), lat5, level(h->pyr, 2), 1, 1, 1, nullptr));
+    h->ops.push_back(conv_op(h, "p4", add_panel(h, { ci++ }), lat4, level(h->pyr, 1), 1, 1, 1, nullptr));
+    h->ops.push_back(conv_op(h, "p3", add_panel(h, { ci++ }), lat3, level(h->pyr, 0), 1, 1, 1, nullptr));
+    h->ops.push_back(conv_op(h, "p6", add_panel(h, { ci++ }), level(h->pyr, 2), level(h->pyr, 3), 2, 1, 0, nullptr));
+    h->ops.push_back(conv_op(h, "p7", add_panel(h, { ci++ }), level(h->pyr, 3), level(h->pyr, 4), 2, 1, 0, nullptr));
+    for (int l = 0; l < 5; ++l) { snprintf(nm, sizeof nm, "p%d", l + 3); h->named[nm] = level(h->pyr, l); }
+    // ---- protonet
+    Buf q = level(h->pyr, 0);
+    for (int i = 0; i < 3; ++i) {
+        Buf y;
+        snprintf(nm, sizeof nm, "proto%d", i);
+        if ((rc = new_buf(h, nm, h->lvl[0], h->lvl[0], 256, &y))) return rc;
+        h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), q, y, 1, 1, 1, nullptr));
+        q = y;
+    }
+    Buf pup, p3b;
+    if ((rc = new_buf(h, "proto_up", h->hp, h->wp, 256, &pup))) return rc;
+    bil("proto_up", q, pup);
+    if ((rc = new_buf(h, "proto3", h->hp, h->wp, 256, &p3b))) return rc;
+    h->ops.push_back(conv_op(h, "proto3", add_panel(h, { ci++ }), pup, p3b, 1, 1, 1, nullptr));
+    if ((rc = new_buf(h, "proto", h->hp, h->wp, 32, &h->proto))) return rc;
+    h->ops.push_back(conv_op(h, "proto", add_panel(h, { ci++ }), p3b, h->proto, 1, 0, 1, nullptr));
+    // ---- shared prediction head: trunk, then box|conf|mask fused along cout
+    const int trunk_panel = add_panel(h, { ci });
+    const int out_panel = add_panel(h, { ci + 1, ci + 2, ci + 3 });
+    ci += 4;
+    for (int l = 0; l < 5; ++l) {
+        snprintf(nm, sizeof nm, "head_t%d", l);
+        h->ops.push_back(conv_op(h, nm, trunk_panel, level(h->pyr, l), level(h->pyr_t, l), 1, 1, 1, nullptr));
+        h->named[nm] = level(h->pyr_t, l);
+        snprintf(nm, sizeof nm, "head_out%d", l);
+        Op o = conv_op(h, nm, out_panel, level(h->pyr_t, l), level(h->heads, l), 1, 1, 0, nullptr);
+        o.tanh_from = 12 + 3 * h->C;
+        h->ops.push_back(o);
+    }
+    if (ci != (int)h->convs.size()) return h->fail(YH_EINVAL, "conv table / graph mismatch");
+    h->flops_per_frame = 0;
+    for (const Op& o : h->ops) h->flops_per_frame += o.flops_per_img;
+    return YH_OK;
+}
+
+void build_priors(yh_engine* h) {
+    static const float ars[3] = { 1.0f, 0.5f, 2.0f };
+    h->priors_host.resize((size_t)h->P * 4);
+    float* q = h->priors_host.data();
+    for (int l = 0; l < 5; ++l) {
+        const float scale = (float)(24 << l) * (float)h->S / 550.0f;
+        const int n = h->lvl[l];
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    const float wv = scale * sqrtf(ars[a]) / (float)h->S;
+                    q[0] = ((float)i + 0.5f) / (float)n;
+                    q[1] = ((float)j + 0.5f) / (float)n;
+                    q[2] = wv;
+                    q[3] = wv;
+                    q += 4;
+                }
+    }
+}
+
+int alloc_tail(yh_engine* h) {
+    const int N = h->cfg.max_batch, Cf = h->C - 1;
+    DetectParams& d = h->det;
+    void* p;
+    int rc;
+#define AL(field, type, count) if ((rc = dev_alloc(h, &p, sizeof(type) * (size_t)(count)))) return rc; d.field = (type*)p
+    AL(cls_count, int, (size_t)N * Cf);
+    AL(cand, uint2, (size_t)N * Cf * h->P);
+    AL(surv_score, float, (size_t)N * Cf * h->cfg.top_k);
+    AL(surv_prior, int, (size_t)N * Cf * h->cfg.top_k);
+    AL(surv_box, float, (size_t)N * Cf * h->cfg.top_k * 4);
+    AL(det_count, int, N);
+    AL(dets, yh_detection, (size_t)N * h->cfg.max_dets);
+    AL(det_crop, float, (size_t)N * h->cfg.max_dets * 4);
+    AL(masks, uint8_t, (size_t)N * h->cfg.max_dets * h->hp * h->wp);
+#undef AL
+    if ((rc = dev_alloc(h, &p, sizeof(float) * (size_t)h->P * 4))) return rc;
+    h->priors_dev = (float*)p;
+    d.priors = h->priors_dev;
+    d.heads = h->heads.d;
+    d.proto = h->proto.d;
+    d.P = h->P; d.cells = h->cells; d.ldh = h->ldh; d.C = h->C; d.hp = h->hp; d.wp = h->wp;
+    d.top_k = h->cfg.top_k; d.max_dets = h->cfg.max_dets;
+    d.conf_thresh = h->cfg.conf_thresh; d.nms_thresh = h->cfg.nms_thresh;
+    return YH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launching
+// ------------------------------------------------------------------------------------------------
+int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
+    const Panel& pn = h->panels[o.panel];
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.x = o.in.d; p.w = pn.w; p.bias = pn.bias; p.y = o.out.d; p.rs_table = pn.rs_table;
+    p.res = o.has_res ? o.res.d : nullptr;
+    p.x_img_stride = o.in.img_stride; p.y_img_stride = o.out.img_stride;
+    p.res_img_stride = o.has_res ? o.res.img_stride : 0;
+    const long long xb = ((long long)(n - 1) * o.in.img_stride + (long long)o.in.h * o.in.w * o.in.c) * 2;
+    if (xb >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+    p.x_bytes = (unsigned)xb;
+    p.N = n; p.H = o.in.h; p.W = o.in.w; p.C = pn.cin_store;
+    p.P = o.P; p.Q = o.Q; p.R = pn.k; p.S = pn.k; p.stride = o.stride; p.pad = o.pad;
+    p.M = n * o.P * o.Q;
+    p.cout8 = round_up(pn.cout, 8);
+    p.ldw = pn.Kpad; p.ksteps = pn.Kpad / 64;
+    p.ldy = o.out.c; p.ldres = o.has_res ? o.res.c : 0;
+    const long long pq = (long long)o.P * o.Q;
+    p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
+    p.act = o.act; p.tanh_from = o.tanh_from;
+    p.n_ch_tiles = pn.coutPad / conv_tile_ch(pn.tile);
+    if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
+    *out = p;
+    return YH_OK;
+}
+
+int launch_op(yh_engine* h, const Op& o, int n) {
+    hipError_t e = hipSuccess;
+    switch (o.kind) {
+        case OP_PRE:
+            e = launch_preprocess(h->in_u8, h->in_f16.d, (long long)n * h->S * h->S, h->stream);
+            break;
+        case OP_CONV: {
+            ConvParams p;
+            int rc = fill_conv_params(h, o, n, &p);
+            if (rc) return rc;
+            e = launch_conv(p, h->panels[o.panel].tile, h->stream);
+            break;
+        }
+        case OP_POOL:
+            e = launch_maxpool3x3s2(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, h->stream);
+            break;
+        case OP_BILINEAR:
+            e = launch_bilinear(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream);
+            break;
+    }
+    if (e != hipSuccess) return h->fail(YH_EHIP, o.label + ": " + hipGetErrorString(e));
+    return YH_OK;
+}
+
+int enqueue_all(yh_engine* h, int n, int with_tail) {
+    for (const Op& o : h->ops) { int rc = launch_op(h, o, n); if (rc) return rc; }
+    if (with_tail) {
+        h->det.n = n;
+        hipError_t e = launch_detect(h->det, h->stream);
+        if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
+    }
+    return YH_OK;
+}
+
+int run(yh_engine* h, int with_tail) {
+    if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
+    if (h->cur_n < 1) return h->fail(YH_ESTATE, "no input set");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int n = h->cur_n;
+    if (!h->cfg.use_graph) return enqueue_all(h, n, with_tail);
+    const int key = n * 2 + (with_tail ? 1 : 0);
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t g = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_all(h, n, with_tail);
+        hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        hipGraphExec_t ge = nullptr;
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        it = h->graphs.emplace(key, ge).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+    return YH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+int alloc_panels(yh_engine* h) {
+    for (Panel& p : h->panels) {
+        void* q;
+        int rc;
+        if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * p.Kpad * 2))) return rc;
+        p.w = (half_t*)q;
+        if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * 4))) return rc;
+        p.bias = (float*)q;
+        if (p.tile == TILE_64x256_SMALLC) {
+            const int nt = p.Kpad / 8;
+            std::vector<int2> t(nt);
+            for (int i = 0; i < nt; ++i) t[i] = i < p.k * p.k ? make_int2(i / p.k, i % p.k) : make_int2(1 << 20, 0);
+            if ((rc = dev_alloc(h, &q, sizeof(int2) * nt))) return rc;
+            p.rs_table = (int2*)q;
+            HIPCHK(h, hipMemcpy(q, t.data(), sizeof(int2) * nt, hipMemcpyHostToDevice));
+        }
+    }
+    return YH_OK;
+}
+
+int check_blob(yh_engine* h, const uint8_t* b, size_t nbytes) {
+    if (nbytes != h->blob_bytes) return h->fail(YH_EWEIGHTS, "weight blob size mismatch");
+    if (memcmp(b, "YHW1", 4) != 0) return h->fail(YH_EWEIGHTS, "weight blob magic mismatch");
+    uint32_t hdr[3];
+    memcpy(hdr, b + 4, 12);
+    if (hdr[0] != h->convs.size() || (int)hdr[1] != h->cfg.backbone || (int)hdr[2] != h->C)
+        return h->fail(YH_EWEIGHTS, "weight blob header does not match the architecture");
+    for (const ConvDesc& d : h->convs) {
+        uint32_t rec[4];
+        memcpy(rec, b + d.blob_w_off - 16, 16);
+        if ((int)rec[0] != d.cout || (int)rec[1] != d.cin || (int)rec[2] != d.k || (int)rec[3] != d.k)
+            return h->fail(YH_EWEIGHTS, "weight blob layer record mismatch");
+    }
+    return YH_OK;
+}
+
+int upload_panels(yh_engine* h, const uint8_t* blob) {
+    HIPCHK(h, hipSetDevice(h->dev));
+    for (Panel& p : h->panels) {
+        std::vector<uint16_t> w((size_t)p.coutPad * p.Kpad, 0);
+        std::vector<float> bias(p.coutPad, 0.0f);
+        int row0 = 0;
+        for (int s : p.src) {
+            const ConvDesc& d = h->convs[s];
+            const uint16_t* src = (const uint16_t*)(blob + d.blob_w_off);
+            const size_t K = (size_t)d.k * d.k * d.cin;
+            for (int o = 0; o < d.cout; ++o) {
+                uint16_t* dst = w.data() + (size_t)(row0 + o) * p.Kpad;
+                if (p.cin_store == d.cin) memcpy(dst, src + (size_t)o * K, K * 2);
+                else
+                    for (int t = 0; t < d.k * d.k; ++t)
+                        for (int c = 0; c < d.cin; ++c) dst[(size_t)t * p.cin_store + c] = src[(size_t)o * K + (size_t)t * d.cin + c];
+            }
+            memcpy(bias.data() + row0, blob + d.blob_b_off, (size_t)d.cout * 4);
+            row0 += d.cout;
+        }
+        HIPCHK(h, hipMemcpy(p.w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(p.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->weights_loaded = true;
+    return YH_OK;
+}
+
+int ensure_out_f32(yh_engine* h, size_t nfloats) {
+    if (nfloats <= h->out_f32_cap) return YH_OK;
+    if (h->out_f32) hipFree(h->out_f32);
+    h->out_f32 = nullptr; h->out_f32_cap = 0;
+    hipError_t e = hipMalloc((void**)&h->out_f32, nfloats * 4);
+    if (e != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc output staging");
+    h->out_f32_cap = nfloats;
+    return YH_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* yh_version(void) { return "yolact-hip 0.1.0 (gfx950, MFMA f16 implicit-GEMM; ABI 1)"; }
+
+void yh_default_config(yh_config* cfg) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->abi_version = YH_ABI_VERSION;
+    cfg->device = 0;
+    cfg->backbone = YH_BACKBONE_R50;
+    cfg->input_size = 550;
+    cfg->max_batch = 1;
+    cfg->num_classes = 81;
+    cfg->top_k = 200;
+    cfg->max_dets = 100;
+    cfg->conf_thresh = 0.05f;
+    cfg->nms_thresh = 0.5f;
+    cfg->use_graph = 1;
+}
+
+const char* yh_last_error(const yh_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int yh_create(const yh_config* cfg, yh_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return YH_EINVAL; }
+    *out = nullptr;
+    if (cfg->abi_version != YH_ABI_VERSION) { g_create_error = "ABI version mismatch"; return YH_EINVAL; }
+    if ((cfg->backbone != YH_BACKBONE_R50 && cfg->backbone != YH_BACKBONE_R101) || cfg->input_size < 64 ||
+        cfg->input_size > 1024 || cfg->max_batch < 1 || cfg->max_batch > 256 || cfg->num_classes < 5 ||
+        cfg->num_classes > 81 || cfg->top_k < 1 || cfg->top_k > 256 || cfg->max_dets < 1 || cfg->max_dets > 128 ||
+        (cfg->num_classes - 1) * cfg->top_k > 16384) {
+        g_create_error = "configuration out of range";
+        return YH_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no such HIP device (the HIP kernel library needs a GPU; there is no CPU fallback)";
+        return YH_EHIP;
+    }
+    yh_engine* h = new yh_engine();
+    h->cfg = *cfg;
+    h->dev = cfg->device;
+    h->S = cfg->input_size;
+    h->C = cfg->num_classes;
+    auto bail = [&](int rc) {
+        g_create_error = h->err;
+        yh_destroy(h);
+        return rc;
+    };
+    hipError_t e = hipSetDevice(h->dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { h->err = std::string("device setup: ") + hipGetErrorString(e); return bail(YH_EHIP); }
+    build_conv_table(h);
+    int rc = build_graph_spec(h);
+    if (rc) return bail(rc);
+    build_priors(h);
+    if ((rc = alloc_tail(h))) return bail(rc);
+    if ((rc = alloc_panels(h))) return bail(rc);
+    e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
+    *out = h;
+    return YH_OK;
+}
+
+void yh_destroy(yh_engine* h) {
+    if (!h) return;
+    hipSetDevice(h->dev);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->out_f32) hipFree(h->out_f32);
+    if (h->frame_dev) hipFree(h->frame_dev);
+    if (h->rs_tmp) hipFree(h->rs_tmp);
+    if (h->cells_dev) hipFree(h->cells_dev);
+    if (h->codes_dev) hipFree(h->codes_dev);
+    if (h->stitch_dev) hipFree(h->stitch_dev);
+    if (h->diverged_dev) hipFree(h->diverged_dev);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+size_t yh_weights_nbytes(const yh_engine* h) { return h ? h->blob_bytes : 0; }
+
+int yh_weights_generate(const yh_engine* hc, uint64_t seed, void* blob_host, size_t nbytes) {
+    yh_engine* h = const_cast<yh_engine*>(hc);
+    if (!h || !blob_host) return YH_EINVAL;
+    if (nbytes != h->blob_bytes) return h->fail(YH_EINVAL, "blob size mismatch");
+    uint8_t* b = (uint8_t*)blob_host;
+    memset(b, 0, nbytes);
+    memcpy(b, "YHW1", 4);
+    const uint32_t hdr[3] = { (uint32_t)h->convs.size(), (uint32_t)h->cfg.backbone, (uint32_t)h->C };
+    memcpy(b + 4, hdr, 12);
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        const ConvDesc& d = h->convs[i];
+        const uint32_t rec[4] = { (uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.k, (uint32_t)d.k };
+        memcpy(b + d.blob_w_off - 16, rec, 16);
+        const size_t ne = (size_t)d.cout * d.k * d.k * d.cin;
+        const float fan_in = (float)(d.k * d.k * d.cin);
+        const float a = d.gain * sqrtf(6.0f / fan_in);
+        uint16_t* w = (uint16_t*)(b + d.blob_w_off);
+        for (size_t e = 0; e < ne; ++e) w[e] = f32_to_f16_bits(unit_rand(seed, i, 0, e) * a);
+        float* bias = (float*)(b + d.blob_b_off);
+        for (int e = 0; e < d.cout; ++e) {
+            float v = unit_rand(seed, i, 1, (uint64_t)e) * 0.1f;
+            if (d.is_conf && (e % h->C) == 0) v = v + 7.5f;
+            bias[e] = v;
+        }
+    }
+    return YH_OK;
+}
+
+int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes) {
+    if (!h || !blob_host) return YH_EINVAL;
+    int rc = check_blob(h, (const uint8_t*)blob_host, nbytes);
+    if (rc) return rc;
+    return upload_panels(h, (const uint8_t*)blob_host);
+}
+
+int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes) {
+    if (!h || !blob_dev) return YH_EINVAL;
+    if (nbytes != h->blob_bytes) return h->fail(YH_EWEIGHTS, "weight blob size mismatch");
+    HIPCHK(h, hipSetDevice(h->dev));
+    std::vector<uint8_t> host(nbytes);
+    HIPCHK(h, hipMemcpy(host.data(), blob_dev, nbytes, hipMemcpyDeviceToHost));
+    int rc = check_blob(h, host.data(), nbytes);
+    if (rc) return rc;
+    return upload_panels(h, host.data());
+}
+
+int yh_input_dims(const yh_engine* h, int32_t dims[4]) {
+    if (!h || !dims) return YH_EINVAL;
+    dims[0] = h->cfg.max_batch; dims[1] = h->S; dims[2] = h->S; dims[3] = 3;
+    return YH_OK;
+}
+
+static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind) {
+    if (!h || !src) return YH_EINVAL;
+    if (n < 1 || n > h->cfg.max_batch) return h->fail(YH_EINVAL, "n_frames out of range");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipMemcpyAsync(h->in_u8, src, (size_t)n * h->S * h->S * 3, kind, h->stream));
+    h->cur_n = n;
+    return YH_OK;
+}
+int yh_set_input_u8(yh_engine* h, const uint8_t* rgb_host, int32_t n) { return set_input(h, rgb_host, n, hipMemcpyHostToDevice); }
+int yh_set_input_u8_device(yh_engine* h, const uint8_t* rgb_dev, int32_t n) { return set_input(h, rgb_dev, n, hipMemcpyDeviceToDevice); }
+
+int yh_invoke(yh_engine* h) { return h ? run(h, 0) : YH_EINVAL; }
+int yh_evaluate(yh_engine* h) { return h ? run(h, 1) : YH_EINVAL; }
+
+int yh_sync(yh_engine* h) {
+    if (!h) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+
+int yh_output_count(const yh_engine* h) { return h ? 5 : YH_EINVAL; }
+
+int yh_output_info(const yh_engine* h, int32_t index, yh_tensor_info* info) {
+    if (!h || !info || index < 0 || index > 4) return YH_EINVAL;
+    static const char* names[5] = { "loc", "conf", "mask", "proto", "cells" };
+    const int n = h->cur_n > 0 ? h->cur_n : h->cfg.max_batch;
+    info->name = names[index];
+    info->kind = index == 4 ? YH_KIND_F32 : YH_KIND_F16;
+    info->scale = 1.0f; info->zero_point = 0;
+    info->dims[0] = n;
+    switch (index) {
+        case 0: info->ndims = 3; info->dims[1] = h->P; info->dims[2] = 4; info->dims[3] = 1; break;
+        case 1: info->ndims = 3; info->dims[1] = h->P; info->dims[2] = h->C; info->dims[3] = 1; break;
+        case 2: info->ndims = 3; info->dims[1] = h->P; info->dims[2] = 32; info->dims[3] = 1; break;
+        case 3: info->ndims = 4; info->dims[1] = h->hp; info->dims[2] = h->wp; info->dims[3] = 32; break;
+        default: info->ndims = 4; info->dims[1] = h->lvl[0]; info->dims[2] = h->lvl[0]; info->dims[3] = h->C; break;
+    }
+    return YH_OK;
+}
+
+int yh_output_read_f32(yh_engine* h, int32_t index, float* dst, size_t nfloats) {
+    if (!h || !dst || index < 0 || index > 4) return YH_EINVAL;
+    if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int n = h->cur_n;
+    size_t need = 0;
+    switch (index) {
+        case 0: need = (size_t)n * h->P * 4; break;
+        case 1: need = (size_t)n * h->P * h->C; break;
+        case 2: need = (size_t)n * h->P * 32; break;
+        case 3: need = (size_t)n * h->hp * h->wp * 32; break;
+        default: need = (size_t)n * h->lvl[0] * h->lvl[0] * h->C; break;
+    }
+    if (nfloats < need) return h->fail(YH_EINVAL, "destination too small");
+    int rc = ensure_out_f32(h, need);
+    if (rc) return rc;
+    hipError_t e;
+    // fused head rows are contiguous over (image, cell): [n*cells][ldh]
+    if (index == 0) e = launch_split_heads(h->heads.d, n, h->cells, h->ldh, h->C, h->out_f32, nullptr, nullptr, h->stream);
+    else if (index == 1) e = launch_split_heads(h->heads.d, n, h->cells, h->ldh, h->C, nullptr, h->out_f32, nullptr, h->stream);
+    else if (index == 2) e = launch_split_heads(h->heads.d, n, h->cells, h->ldh, h->C, nullptr, nullptr, h->out_f32, h->stream);
+    else if (index == 3) e = launch_f16_to_f32(h->proto.d, h->out_f32, (long long)need, h->stream);
+    else e = launch_cells_f32(h->heads.d, n, h->cells, h->lvl[0] * h->lvl[0], h->ldh, h->C, h->out_f32, h->stream);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("output convert: ") + hipGetErrorString(e));
+    HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, need * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+
+const void* yh_output_device_ptr(const yh_engine* h, int32_t index) {
+    if (!h) return nullptr;
+    if (index >= 0 && index <= 2) return h->heads.d;  // fused rows: 12 box | 3C conf | 96 mask, row stride ldh
+    if (index == 3) return h->proto.d;
+    return nullptr;
+}
+
+int yh_read_detections(yh_engine* h, int32_t frame, int32_t* count, yh_detection* dets, int32_t cap,
+                       uint8_t* masks, size_t masks_cap) {
+    if (!h || !count) return YH_EINVAL;
+    if (frame < 0 || frame >= h->cur_n) return h->fail(YH_EINVAL, "frame out of range");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int nd = 0;
+    HIPCHK(h, hipMemcpy(&nd, h->det.det_count + frame, 4, hipMemcpyDeviceToHost));
+    *count = nd;
+    if (dets) {
+        if (cap < nd) return h->fail(YH_EINVAL, "dets capacity too small");
+        HIPCHK(h, hipMemcpy(dets, h->det.dets + (size_t)frame * h->cfg.max_dets, sizeof(yh_detection) * (size_t)nd, hipMemcpyDeviceToHost));
+    }
+    if (masks) {
+        const size_t px = (size_t)h->hp * h->wp;
+        if (masks_cap < px * nd) return h->fail(YH_EINVAL, "masks capacity too small");
+        HIPCHK(h, hipMemcpy(masks, h->det.masks + (size_t)frame * h->cfg.max_dets * px, px * nd, hipMemcpyDeviceToHost));
+    }
+    return YH_OK;
+}
+
+int yh_proto_dims(const yh_engine* h, int32_t dims[2]) {
+    if (!h || !dims) return YH_EINVAL;
+    dims[0] = h->hp; dims[1] = h->wp;
+    return YH_OK;
+}
+int yh_num_priors(const yh_engine* h) { return h ? h->P : YH_EINVAL; }
+int yh_read_priors(const yh_engine* h, float* dst, size_t nfloats) {
+    if (!h || !dst || nfloats < h->priors_host.size()) return YH_EINVAL;
+    memcpy(dst, h->priors_host.data(), h->priors_host.size() * 4);
+    return YH_OK;
+}
+double yh_flops_per_frame(const yh_engine* h) { return h ? h->flops_per_frame : 0.0; }
+
+}  // extern "C"
+
+// ================================================================================================
+// C ABI, part 2: reference-compat path, measurement hooks, single-op entry points
+// ================================================================================================
+namespace {
+
+int grow(yh_engine* h, void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return YH_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipMalloc(p, bytes) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc scratch");
+    *cap = bytes;
+    return YH_OK;
+}
+
+int ensure_compat(yh_engine* h, int n_tiles) {
+    const int grid = h->S / 8;
+    if (!h->cells_dev) {
+        const size_t nt = (size_t)h->cfg.max_batch;
+        if (hipMalloc((void**)&h->cells_dev, nt * grid * grid * h->C * 4) != hipSuccess ||
+            hipMalloc((void**)&h->codes_dev, nt * grid * grid * 4) != hipSuccess ||
+            hipMalloc((void**)&h->stitch_dev, nt * h->S * h->S * 4) != hipSuccess ||
+            hipMalloc((void**)&h->diverged_dev, nt * 4) != hipSuccess)
+            return h->fail(YH_ENOMEM, "hipMalloc compat scratch");
+    }
+    (void)n_tiles;
+    return YH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_postprocess_cells(yh_engine* h, const float* cells_host, int32_t n_tiles, uint32_t* out_host, int32_t mode) {
+    if (!h || !cells_host || !out_host) return YH_EINVAL;
+    if (h->S % 8 != 0 || h->S / 8 > 64) return h->fail(YH_EINVAL, "input_size must be a multiple of 8 (<= 512) for the cell postprocess");
+    if (n_tiles < 1 || n_tiles > h->cfg.max_batch) return h->fail(YH_EINVAL, "n_tiles out of range");
+    if (mode != YH_COMPAT_STRICT && mode != YH_COMPAT_SANE) return h->fail(YH_EINVAL, "bad compat mode");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = ensure_compat(h, n_tiles);
+    if (rc) return rc;
+    const int grid = h->S / 8;
+    const size_t nc = (size_t)n_tiles * grid * grid;
+    HIPCHK(h, hipMemcpyAsync(h->cells_dev, cells_host, nc * h->C * 4, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_cells_postprocess(h->cells_dev, n_tiles, grid, h->C, mode, h->codes_dev, h->diverged_dev, h->stream);
+    if (e == hipSuccess) e = launch_upsample_codes(h->codes_dev, n_tiles, grid, h->stitch_dev, 0, h->stream);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("cells_postprocess: ") + hipGetErrorString(e));
+    std::vector<int> div(n_tiles);
+    HIPCHK(h, hipMemcpyAsync(div.data(), h->diverged_dev, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int d : div)
+        if (d) return h->fail(YH_EDIVERGE, "reference flood fill (yolact.rs:57-78) does not terminate on this input");
+    HIPCHK(h, hipMemcpy(out_host, h->stitch_dev, (size_t)n_tiles * h->S * h->S * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+int yh_resize_triangle_rgb8(yh_engine* h, const uint8_t* src, int32_t sw, int32_t sh, uint8_t* dst, int32_t dw, int32_t dh) {
+    if (!h || !src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return YH_EINVAL;
+    if (sw == dw && sh == dh) { memcpy(dst, src, (size_t)sw * sh * 3); return YH_OK; }  // image::resize copies
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = grow(h, (void**)&h->rs_tmp, &h->rs_tmp_cap, (size_t)sw * dh * 3 * 4);
+    if (rc) return rc;
+    uint8_t *s_dev = nullptr, *d_dev = nullptr;
+    HIPCHK(h, hipMalloc((void**)&s_dev, (size_t)sw * sh * 3));
+    if (hipMalloc((void**)&d_dev, (size_t)dw * dh * 3) != hipSuccess) { hipFree(s_dev); return h->fail(YH_ENOMEM, "hipMalloc"); }
+    hipError_t e = hipMemcpyAsync(s_dev, src, (size_t)sw * sh * 3, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_resize_v_rgb8(s_dev, sw, sh, h->rs_tmp, dh, h->stream);
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, sw, dh, d_dev, dw, 0, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_dev, (size_t)dw * dh * 3, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(s_dev); hipFree(d_dev);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("resize: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, int32_t mode) {
+    if (!h || !frame || w < 1 || hh < 1) return YH_EINVAL;
+    if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
+    if (h->S % 8 != 0 || h->S / 8 > 64 || h->cfg.max_batch < 2)
+        return h->fail(YH_EINVAL, "classify needs input_size % 8 == 0 (<= 512) and max_batch >= 2");
+    if (mode != YH_COMPAT_STRICT && mode != YH_COMPAT_SANE) return h->fail(YH_EINVAL, "bad compat mode");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int S = h->S, grid = S / 8;
+    int rc = ensure_compat(h, 2);
+    if (rc) return rc;
+    const size_t npx = (size_t)w * hh;
+    if ((rc = grow(h, (void**)&h->frame_dev, &h->frame_cap, npx * 4))) return rc;
+    const size_t tmp_need = (size_t)3 * 4 * ((size_t)w * S > (size_t)2 * S * hh ? (size_t)w * S : (size_t)2 * S * hh);
+    if ((rc = grow(h, (void**)&h->rs_tmp, &h->rs_tmp_cap, tmp_need))) return rc;
+    // yolact.rs:195-214: unpack, resize_exact(2S, S), crop two tiles -> engine input (batch of 2)
+    HIPCHK(h, hipMemcpyAsync(h->frame_dev, frame, npx * 4, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_resize_v_u32(h->frame_dev, w, hh, h->rs_tmp, S, h->stream);
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->in_u8, 2 * S, 1, h->stream);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("classify pre: ") + hipGetErrorString(e));
+    h->cur_n = 2;
+    // yolact.rs:216-217 + :163: the two tiles as one batch
+    if ((rc = run(h, 0))) return rc;
+    // yolact.rs:169-189 (outputs -> f32, results[4]) and :90-131
+    e = launch_cells_f32(h->heads.d, 2, h->cells, grid * grid, h->ldh, h->C, h->cells_dev, h->stream);
+    if (e == hipSuccess) e = launch_cells_postprocess(h->cells_dev, 2, grid, h->C, mode, h->codes_dev, h->diverged_dev, h->stream);
+    // yolact.rs:219-220 stitch, :222-231 resize the class-code image back, :233 overwrite
+    if (e == hipSuccess) e = launch_upsample_codes(h->codes_dev, 2, grid, h->stitch_dev, 1, h->stream);
+    if (e == hipSuccess) e = launch_resize_v_u32(h->stitch_dev, 2 * S, S, h->rs_tmp, hh, h->stream);
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, 2 * S, hh, h->frame_dev, w, 2, h->stream);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("classify post: ") + hipGetErrorString(e));
+    int div[2] = { 0, 0 };
+    HIPCHK(h, hipMemcpyAsync(div, h->diverged_dev, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (div[0] || div[1]) return h->fail(YH_EDIVERGE, "reference flood fill (yolact.rs:57-78) does not terminate on this frame");
+    HIPCHK(h, hipMemcpy(frame, h->frame_dev, npx * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+// ---- measurement hooks -------------------------------------------------------------------------
+int yh_profile_launch_count(const yh_engine* h, int32_t with_tail) {
+    if (!h) return YH_EINVAL;
+    return (int)h->ops.size() + (with_tail ? detect_launch_count() : 0);
+}
+
+int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, double* flops, double* bytes, const char** names) {
+    if (!h || !ms || reps < 1) return YH_EINVAL;
+    if (!h->weights_loaded || h->cur_n < 1) return h->fail(YH_ESTATE, "weights and input must be set");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int n = h->cur_n, nl = yh_profile_launch_count(h, with_tail), nops = (int)h->ops.size();
+    std::vector<hipEvent_t> ev((size_t)nl * 2);
+    for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+    std::vector<double> acc(nl, 0.0);
+    h->det.n = n;
+    int rc = YH_OK;
+    for (int r = 0; r < reps && rc == YH_OK; ++r) {
+        for (int i = 0; i < nl && rc == YH_OK; ++i) {
+            hipEventRecord(ev[2 * i], h->stream);
+            if (i < nops) rc = launch_op(h, h->ops[i], n);
+            else if (launch_detect_stage(h->det, i - nops, h->stream) != hipSuccess) rc = h->fail(YH_EHIP, "detect stage launch failed");
+            hipEventRecord(ev[2 * i + 1], h->stream);
+        }
+        if (rc) break;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = h->fail(YH_EHIP, "sync failed in profile run"); break; }
+        for (int i = 0; i < nl; ++i) { float t = 0; hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]); acc[i] += t; }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    if (rc) return rc;
+    for (int i = 0; i < nl; ++i) {
+        ms[i] = (float)(acc[i] / reps);
+        const bool isop = i < nops;
+        if (flops) flops[i] = isop ? h->ops[i].flops_per_img * n : 0.0;
+        if (bytes) bytes[i] = isop ? h->ops[i].bytes_per_img * n + h->ops[i].bytes_fixed : 0.0;
+        if (names) names[i] = isop ? h->ops[i].label.c_str() : detect_stage_name(i - nops);
+    }
+    return YH_OK;
+}
+
+int yh_time_steps(yh_engine* h, int32_t with_tail, int32_t steps, float* ms_total) {
+    if (!h || !ms_total || steps < 1) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < steps; ++i) { int rc = run(h, with_tail); if (rc) return rc; }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
+    return YH_OK;
+}
+
+// ---- single-op entry points (tests) ------------------------------------------------------------
+int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint16_t* w,
+                     const float* bias, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                     const uint16_t* residual, int32_t act, uint16_t* y) {
+    if (!h || !x || !w || !bias || !y) return YH_EINVAL;
+    if (kh != kw || kh < 1 || stride < 1 || n < 1 || (cin != 3 && cin % 64 != 0) || (act < 0 || act > 2))
+        return h->fail(YH_EINVAL, "conv op: need square kernel and cin == 3 or cin % 64 == 0");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int cs = cin == 3 ? 8 : cin, k = kh;
+    const int P = out_dim(hh, k, stride, pad), Q = out_dim(ww, k, stride, pad);
+    if (P < 1 || Q < 1) return h->fail(YH_EINVAL, "conv op: empty output");
+    ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
+    const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
+    const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
+    // host-side staging: pad input channels, repack weights, pad output rows to cout8
+    std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
+    for (size_t i = 0; i < (size_t)n * hh * ww; ++i) memcpy(&xs[i * cs], &x[i * cin], (size_t)cin * 2);
+    for (int o = 0; o < cout; ++o)
+        for (int t = 0; t < k * k; ++t) memcpy(&wp[(size_t)o * Kpad + (size_t)t * cs], &w[((size_t)o * k * k + t) * cin], (size_t)cin * 2);
+    std::vector<float> bp(coutPad, 0.0f);
+    memcpy(bp.data(), bias, (size_t)cout * 4);
+    const size_t M = (size_t)n * P * Q;
+    std::vector<uint16_t> rs, ys(M * cout8);
+    if (residual) { rs.assign(M * cout8, 0); for (size_t m = 0; m < M; ++m) memcpy(&rs[m * cout8], &residual[m * cout], (size_t)cout * 2); }
+    std::vector<int2> tab;
+    if (cin == 3) { tab.resize(Kpad / 8); for (int i = 0; i < Kpad / 8; ++i) tab[i] = i < k * k ? make_int2(i / k, i % k) : make_int2(1 << 20, 0); }
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dr = nullptr, *dt = nullptr;
+    hipError_t e = hipMalloc(&dx, xs.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&dw, wp.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&db, bp.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&dy, ys.size() * 2);
+    if (e == hipSuccess && residual) e = hipMalloc(&dr, rs.size() * 2);
+    if (e == hipSuccess && cin == 3) e = hipMalloc(&dt, tab.size() * sizeof(int2));
+    if (e == hipSuccess) e = hipMemcpy(dx, xs.data(), xs.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dw, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && residual) e = hipMemcpy(dr, rs.data(), rs.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess && cin == 3) e = hipMemcpy(dt, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dy, 0xFF, ys.size() * 2);
+    if (e == hipSuccess) {
+        ConvParams p;
+        memset(&p, 0, sizeof p);
+        p.x = (const half_t*)dx; p.w = (const half_t*)dw; p.bias = (const float*)db; p.res = (const half_t*)dr; p.y = (half_t*)dy;
+        p.rs_table = (const int2*)dt;
+        p.x_img_stride = (long long)hh * ww * cs; p.y_img_stride = (long long)P * Q * cout8; p.res_img_stride = p.y_img_stride;
+        p.x_bytes = (unsigned)(xs.size() * 2);
+        p.N = n; p.H = hh; p.W = ww; p.C = cs; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
+        p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad; p.ksteps = Kpad / 64; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
+        p.act = act == 1 ? 1 : 0; p.tanh_from = act == 2 ? 0 : INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile);
+        e = launch_conv(p, tile, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(ys.data(), dy, ys.size() * 2, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dw); hipFree(db); hipFree(dy); if (dr) hipFree(dr); if (dt) hipFree(dt);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("conv op: ") + hipGetErrorString(e));
+    for (size_t m = 0; m < M; ++m) memcpy(&y[m * cout], &ys[m * cout8], (size_t)cout * 2);
+    return YH_OK;
+}
+
+int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t c, int32_t ho, int32_t wo, uint16_t* y) {
+    if (!h || !x || !y || c % 8 != 0 || n < 1) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    const size_t ni = (size_t)n * hh * ww * c, no = (size_t)n * ho * wo * c;
+    void *dx = nullptr, *dy = nullptr;
+    hipError_t e = hipMalloc(&dx, ni * 2);
+    if (e == hipSuccess) e = hipMalloc(&dy, no * 2);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, ni * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_bilinear((const half_t*)dx, (half_t*)dy, n, hh, ww, c, ho, wo, (long long)hh * ww * c, (long long)ho * wo * c, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy, no * 2, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("bilinear op: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t c, uint16_t* y) {
+    if (!h || !x || !y || c % 8 != 0 || n < 1) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int ho = out_dim(hh, 3, 2, 1), wo = out_dim(ww, 3, 2, 1);
+    const size_t ni = (size_t)n * hh * ww * c, no = (size_t)n * ho * wo * c;
+    void *dx = nullptr, *dy = nullptr;
+    hipError_t e = hipMalloc(&dx, ni * 2);
+    if (e == hipSuccess) e = hipMalloc(&dy, no * 2);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, ni * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_maxpool3x3s2((const half_t*)dx, (half_t*)dy, n, hh, ww, c, ho, wo, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy, no * 2, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("maxpool op: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+int yh_op_detect(yh_engine* h, const uint16_t* loc, const uint16_t* conf, const uint16_t* mask, const uint16_t* proto, int32_t n) {
+    if (!h || !loc || !conf || !mask || !proto) return YH_EINVAL;
+    if (n < 1 || n > h->cfg.max_batch) return h->fail(YH_EINVAL, "n out of range");
+    HIPCHK(h, hipSetDevice(h->dev));
+    // interleave into the fused head rows [n][cells][ldh]
+    const int C = h->C, ldh = h->ldh;
+    std::vector<uint16_t> rows((size_t)n * h->cells * ldh, 0);
+    for (size_t r = 0; r < (size_t)n * h->cells; ++r) {
+        uint16_t* d = &rows[r * ldh];
+        memcpy(d, &loc[r * 12], 24);
+        memcpy(d + 12, &conf[r * 3 * C], (size_t)3 * C * 2);
+        memcpy(d + 12 + 3 * C, &mask[r * 96], 192);
+    }
+    HIPCHK(h, hipMemcpy(h->heads.d, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->proto.d, proto, (size_t)n * h->hp * h->wp * 32 * 2, hipMemcpyHostToDevice));
+    h->cur_n = n;
+    h->det.n = n;
+    hipError_t e = launch_detect(h->det, h->stream);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+
+}  // extern "C"

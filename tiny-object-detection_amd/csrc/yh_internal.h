@@ -1,0 +1,132 @@
+// yh_internal.h — shared declarations of libyolact_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/yolact_hip.h"
+
+namespace yh {
+
+typedef _Float16 half_t;
+
+// ---------------------------------------------------------------------------------------------
+// Convolution as implicit GEMM (conv_igemm.hip).
+//   D[ch][m] = sum_k Wt[ch][k] * X[m][k],  m = (n, p, q) row-major,  k = ((r*S + s)*C + c).
+// Activations are NHWC f16 with C a multiple of 8 (C >= 64: multiple of 64; C == 8: "small-C"
+// mode, one (r,s) tap per 16-byte chunk, taps listed in rs_table). Weights are a zero-padded
+// [coutPad][Kpad] f16 panel, Kpad a multiple of 64, coutPad a multiple of the channel tile.
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const half_t* x;      // input base (first image, first pixel of the addressed slice)
+    const half_t* w;      // weight panel [coutPad][ldw]
+    const float* bias;    // [coutPad] (zero padded)
+    const half_t* res;    // residual or nullptr
+    half_t* y;            // output base
+    const int2* rs_table; // small-C mode: (r, s) per 16-byte chunk index; r = 1<<20 marks padding
+    long long x_img_stride, y_img_stride, res_img_stride; // elements per image
+    unsigned x_bytes;     // bytes addressable from x (buffer bounds: taps outside read 0)
+    int N, H, W, C;       // input
+    int P, Q;             // output spatial
+    int R, S, stride, pad;
+    int M;                // N*P*Q
+    int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
+    int ldw;              // Kpad
+    int ksteps;           // Kpad / 64
+    int ldy, ldres;       // row strides in elements
+    int y_dense;          // 1: y offset = m*ldy (no per-row division)
+    int act;              // 0 none, 1 relu
+    int tanh_from;        // channels >= tanh_from get tanh (INT_MAX: none)
+    int n_ch_tiles;
+};
+
+enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4 };
+int conv_tile_ch(ConvTile t);
+int conv_tile_m(ConvTile t);
+const char* conv_tile_symbol(ConvTile t);
+hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise / gather kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_preprocess(const uint8_t* rgb, half_t* out8, long long npix, hipStream_t s);
+hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s);
+hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
+                           long long x_img_stride, long long y_img_stride, hipStream_t s);
+// heads [n][cells][ldh] f16 -> loc/conf/mask/cells split as f32 (output reads only)
+hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc,
+                              float* conf, float* mask, hipStream_t s);
+hipError_t launch_f16_to_f32(const half_t* x, float* y, long long n, hipStream_t s);
+hipError_t launch_cells_f32(const half_t* heads, int n, int cells_img, int cells_l0, int ldh, int C,
+                            float* out, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Detection tail (detect.hip)
+// ---------------------------------------------------------------------------------------------
+struct DetectParams {
+    const half_t* heads;  // [n][cells][ldh]: 12 box | 3*C conf | 96 mask per cell
+    const half_t* proto;  // [n][hp][wp][32]
+    const float* priors;  // [P][4]
+    int n, P, cells, ldh, C, hp, wp, top_k, max_dets;
+    float conf_thresh, nms_thresh;
+    // workspaces
+    int* cls_count;       // [n][C-1]
+    uint2* cand;          // [n][C-1][P]  {score bits, prior}
+    float* surv_score;    // [n][(C-1)*top_k]  (-1: empty)
+    int* surv_prior;      // same
+    float* surv_box;      // [..][4]
+    // outputs
+    int* det_count;       // [n]
+    yh_detection* dets;   // [n][max_dets]
+    float* det_crop;      // [n][max_dets][4]  xa, xb, ya, yb
+    uint8_t* masks;       // [n][max_dets][hp*wp]
+};
+hipError_t launch_detect(const DetectParams& p, hipStream_t s);
+int detect_launch_count();
+const char* detect_stage_name(int stage);
+hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Reference-compat kernels (refpath.hip): yolact.rs pre/post-processing on device
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_resize_v_u32(const uint32_t* src, int sw, int sh, float* tmp, int dh, hipStream_t s);
+hipError_t launch_resize_v_rgb8(const uint8_t* src, int sw, int sh, float* tmp, int dh, hipStream_t s);
+// horizontal pass; mode 0: RGB8 image [dh][dw][3]; mode 1: tile-split RGB8 [dw/S][S][S][3] with
+// S = dh; mode 2: packed u32 r<<24|g<<16|b<<8
+hipError_t launch_resize_h(const float* tmp, int sw, int dh, void* dst, int dw, int mode, hipStream_t s);
+// postprocess (yolact.rs:90-131) per tile; heads-derived logits; writes cell codes and flags
+hipError_t launch_cells_postprocess(const float* cells, int n_tiles, int grid, int C, int mode,
+                                    uint32_t* codes, int* diverged, hipStream_t s);
+// x8 nearest upsample of cell codes into a [n_tiles][S][S] u32 image, or stitched [S][n_tiles*S]
+hipError_t launch_upsample_codes(const uint32_t* codes, int n_tiles, int grid, uint32_t* out,
+                                 int stitched, hipStream_t s);
+
+// device spec functions shared by kernels (bit-exact restatement of DESIGN.md §Spec-exp)
+__device__ __forceinline__ float spec_expf(float x) {
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
+    float t = __fmul_rn(x, 1.44269504088896341f);
+    float n = rintf(t);
+    float r = __fmaf_rn(n, -0.693359375f, x);
+    r = __fmaf_rn(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __fmaf_rn(p, r, 1.3981999507e-3f);
+    p = __fmaf_rn(p, r, 8.3334519073e-3f);
+    p = __fmaf_rn(p, r, 4.1665795894e-2f);
+    p = __fmaf_rn(p, r, 1.6666665459e-1f);
+    p = __fmaf_rn(p, r, 5.0000001201e-1f);
+    float r2 = __fmul_rn(r, r);
+    float y = __fmaf_rn(p, r2, r);
+    y = __fadd_rn(y, 1.0f);
+    int bits = __float_as_int(y) + ((int)n << 23);
+    return __int_as_float(bits);
+}
+__device__ __forceinline__ float spec_tanhf(float x) {
+    float a = fabsf(x);
+    float e = spec_expf(__fmul_rn(-2.0f, a));
+    float t = __fdiv_rn(__fsub_rn(1.0f, e), __fadd_rn(1.0f, e));
+    return x < 0.0f ? -t : t;
+}
+
+}  // namespace yh

@@ -1,0 +1,290 @@
+"""ctypes binding of include/yolact_hip.h (the C ABI of libyolact_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+OK, EINVAL, EHIP, ENOMEM, EWEIGHTS, ESTATE, EDIVERGE, EOVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
+COMPAT_STRICT, COMPAT_SANE = 0, 1
+
+
+class YhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"yolact_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("backbone", C.c_int32),
+                ("input_size", C.c_int32), ("max_batch", C.c_int32), ("num_classes", C.c_int32),
+                ("top_k", C.c_int32), ("max_dets", C.c_int32), ("conf_thresh", C.c_float),
+                ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int32), ("ndims", C.c_int32), ("dims", C.c_int32 * 4),
+                ("scale", C.c_float), ("zero_point", C.c_int32)]
+
+
+class Detection(C.Structure):
+    _fields_ = [("class_id", C.c_int32), ("prior", C.c_int32), ("score", C.c_float), ("box", C.c_float * 4)]
+
+
+def lib_path():
+    return os.path.join(_PKG, "lib", "libyolact_hip.so")
+
+
+# every symbol include/yolact_hip.h declares: (name, restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+SYMBOLS = [
+    ("yh_version", C.c_char_p, []),
+    ("yh_default_config", None, [C.POINTER(Config)]),
+    ("yh_create", _i, [C.POINTER(Config), C.POINTER(_vp)]),
+    ("yh_destroy", None, [_vp]),
+    ("yh_last_error", C.c_char_p, [_vp]),
+    ("yh_weights_nbytes", _sz, [_vp]),
+    ("yh_weights_generate", _i, [_vp, C.c_uint64, _vp, _sz]),
+    ("yh_load_weights_host", _i, [_vp, _vp, _sz]),
+    ("yh_load_weights_device", _i, [_vp, _vp, _sz]),
+    ("yh_input_dims", _i, [_vp, C.POINTER(_i * 4)]),
+    ("yh_set_input_u8", _i, [_vp, _vp, _i]),
+    ("yh_set_input_u8_device", _i, [_vp, _vp, _i]),
+    ("yh_invoke", _i, [_vp]),
+    ("yh_sync", _i, [_vp]),
+    ("yh_output_count", _i, [_vp]),
+    ("yh_output_info", _i, [_vp, _i, C.POINTER(TensorInfo)]),
+    ("yh_output_read_f32", _i, [_vp, _i, _vp, _sz]),
+    ("yh_output_device_ptr", _vp, [_vp, _i]),
+    ("yh_evaluate", _i, [_vp]),
+    ("yh_read_detections", _i, [_vp, _i, C.POINTER(_i), _vp, _i, _vp, _sz]),
+    ("yh_proto_dims", _i, [_vp, C.POINTER(_i * 2)]),
+    ("yh_num_priors", _i, [_vp]),
+    ("yh_read_priors", _i, [_vp, _vp, _sz]),
+    ("yh_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
+    ("yh_postprocess_cells", _i, [_vp, _vp, _i, _vp, _i]),
+    ("yh_resize_triangle_rgb8", _i, [_vp, _vp, _i, _i, _vp, _i, _i]),
+    ("yh_profile_launch_count", _i, [_vp, _i]),
+    ("yh_profile_run", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("yh_time_steps", _i, [_vp, _i, _i, C.POINTER(_f)]),
+    ("yh_flops_per_frame", C.c_double, [_vp]),
+    ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    ("yh_op_maxpool3x3s2_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    ("yh_op_detect", _i, [_vp, _vp, _vp, _vp, _vp, _i]),
+]
+
+
+def load_library():
+    """Loads libyolact_hip.so. Raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(there is no CPU fallback for the HIP kernel library)")
+        L = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the ABI symbol is absent
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def version():
+    return load_library().yh_version().decode()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f16_bits(a):
+    return np.ascontiguousarray(np.asarray(a, np.float32).astype(np.float16)).view(np.uint16)
+
+
+def _bits_f32(b, shape):
+    return b.view(np.float16).astype(np.float32).reshape(shape)
+
+
+class Engine:
+    """RAII wrapper of one yh_engine handle."""
+
+    def __init__(self, input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100,
+                 conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0):
+        self.L = load_library()
+        cfg = Config()
+        self.L.yh_default_config(C.byref(cfg))
+        cfg.device, cfg.backbone, cfg.input_size, cfg.max_batch = device, backbone, input_size, max_batch
+        cfg.num_classes, cfg.top_k, cfg.max_dets = num_classes, top_k, max_dets
+        cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = conf_thresh, nms_thresh, 1 if use_graph else 0
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.L.yh_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise YhError(rc, self.L.yh_last_error(None).decode())
+        self.h = h
+        self.S, self.C, self.max_batch = input_size, num_classes, max_batch
+        self.P = self.L.yh_num_priors(self.h)
+        d = (C.c_int32 * 2)()
+        self.L.yh_proto_dims(self.h, C.byref(d))
+        self.hp, self.wp = d[0], d[1]
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.yh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise YhError(rc, self.L.yh_last_error(self.h).decode())
+
+    # ---- weights
+    def weights_nbytes(self):
+        return self.L.yh_weights_nbytes(self.h)
+
+    def generate_weights(self, seed=1):
+        blob = np.zeros(self.weights_nbytes(), np.uint8)
+        self._chk(self.L.yh_weights_generate(self.h, seed, _p(blob), blob.size))
+        return blob
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._chk(self.L.yh_load_weights_host(self.h, _p(blob), blob.size))
+
+    def load_weights_device(self, dev_ptr, nbytes):
+        self._chk(self.L.yh_load_weights_device(self.h, C.c_void_p(dev_ptr), nbytes))
+
+    # ---- interpreter-shaped surface
+    def input_dims(self):
+        d = (C.c_int32 * 4)()
+        self._chk(self.L.yh_input_dims(self.h, C.byref(d)))
+        return tuple(d)
+
+    def set_input(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        n = rgb.shape[0]
+        assert rgb.shape == (n, self.S, self.S, 3), rgb.shape
+        self._chk(self.L.yh_set_input_u8(self.h, _p(rgb), n))
+        self.n = n
+
+    def set_input_device(self, dev_ptr, n):
+        self._chk(self.L.yh_set_input_u8_device(self.h, C.c_void_p(dev_ptr), n))
+        self.n = n
+
+    def invoke(self):
+        self._chk(self.L.yh_invoke(self.h))
+
+    def evaluate(self):
+        self._chk(self.L.yh_evaluate(self.h))
+
+    def sync(self):
+        self._chk(self.L.yh_sync(self.h))
+
+    def output_count(self):
+        return self.L.yh_output_count(self.h)
+
+    def output_info(self, i):
+        ti = TensorInfo()
+        self._chk(self.L.yh_output_info(self.h, i, C.byref(ti)))
+        return dict(name=ti.name.decode(), kind=ti.kind, dims=tuple(ti.dims[:ti.ndims]), scale=ti.scale,
+                    zero_point=ti.zero_point)
+
+    def output(self, i):
+        info = self.output_info(i)
+        out = np.empty(info["dims"], np.float32)
+        self._chk(self.L.yh_output_read_f32(self.h, i, _p(out), out.size))
+        return out
+
+    def priors(self):
+        out = np.empty((self.P, 4), np.float32)
+        self._chk(self.L.yh_read_priors(self.h, _p(out), out.size))
+        return out
+
+    def detections(self, frame, want_masks=True):
+        nd = C.c_int32()
+        dets = (Detection * self.cfg.max_dets)()
+        masks = np.zeros((self.cfg.max_dets, self.hp, self.wp), np.uint8) if want_masks else None
+        self._chk(self.L.yh_read_detections(self.h, frame, C.byref(nd), C.cast(dets, C.c_void_p), self.cfg.max_dets,
+                                            _p(masks) if want_masks else None, masks.size if want_masks else 0))
+        out = [dict(class_id=d.class_id, prior=d.prior, score=d.score, box=tuple(d.box)) for d in dets[:nd.value]]
+        return out, (masks[:nd.value] if want_masks else None)
+
+    def flops_per_frame(self):
+        return self.L.yh_flops_per_frame(self.h)
+
+    # ---- reference-compat path
+    def classify_frame(self, frame_u32, width, height, mode=COMPAT_STRICT):
+        """In place on a C-contiguous uint32 array of width*height packed pixels."""
+        assert frame_u32.dtype == np.uint32 and frame_u32.flags.c_contiguous and frame_u32.size == width * height
+        self._chk(self.L.yh_classify_frame_u32(self.h, _p(frame_u32), width, height, mode))
+
+    def postprocess_cells(self, cells, mode=COMPAT_STRICT):
+        cells = np.ascontiguousarray(cells, np.float32)
+        n = cells.shape[0]
+        out = np.zeros((n, self.S, self.S), np.uint32)
+        self._chk(self.L.yh_postprocess_cells(self.h, _p(cells), n, _p(out), mode))
+        return out
+
+    def resize_triangle(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        sh, sw = src.shape[:2]
+        out = np.empty((dh, dw, 3), np.uint8)
+        self._chk(self.L.yh_resize_triangle_rgb8(self.h, _p(src), sw, sh, _p(out), dw, dh))
+        return out
+
+    # ---- measurement hooks
+    def profile(self, with_tail=True, reps=5):
+        nl = self.L.yh_profile_launch_count(self.h, 1 if with_tail else 0)
+        ms = np.zeros(nl, np.float32)
+        fl = np.zeros(nl, np.float64)
+        by = np.zeros(nl, np.float64)
+        names = (C.c_char_p * nl)()
+        self._chk(self.L.yh_profile_run(self.h, 1 if with_tail else 0, reps, _p(ms), _p(fl), _p(by), C.cast(names, C.c_void_p)))
+        return [dict(name=names[i].decode(), ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(nl)]
+
+    def time_steps(self, steps, with_tail=True):
+        ms = C.c_float()
+        self._chk(self.L.yh_time_steps(self.h, 1 if with_tail else 0, steps, C.byref(ms)))
+        return ms.value
+
+    # ---- single ops (tests)
+    def op_conv2d(self, x, w, bias, stride=1, pad=0, residual=None, act=0):
+        n, hh, ww, cin = x.shape
+        cout, kh, kw, _ = w.shape
+        ho, wo = (hh + 2 * pad - kh) // stride + 1, (ww + 2 * pad - kw) // stride + 1
+        xb, wb = _f16_bits(x), _f16_bits(w)
+        bias = np.ascontiguousarray(bias, np.float32)
+        rb = _f16_bits(residual) if residual is not None else None
+        y = np.zeros((n, ho, wo, cout), np.uint16)
+        self._chk(self.L.yh_op_conv2d_f16(self.h, _p(xb), n, hh, ww, cin, _p(wb), _p(bias), cout, kh, kw, stride, pad,
+                                          _p(rb) if rb is not None else None, act, _p(y)))
+        return _bits_f32(y, y.shape)
+
+    def op_bilinear(self, x, ho, wo):
+        n, hh, ww, c = x.shape
+        xb = _f16_bits(x)
+        y = np.zeros((n, ho, wo, c), np.uint16)
+        self._chk(self.L.yh_op_bilinear_f16(self.h, _p(xb), n, hh, ww, c, ho, wo, _p(y)))
+        return _bits_f32(y, y.shape)
+
+    def op_maxpool(self, x):
+        n, hh, ww, c = x.shape
+        ho, wo = (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1
+        xb = _f16_bits(x)
+        y = np.zeros((n, ho, wo, c), np.uint16)
+        self._chk(self.L.yh_op_maxpool3x3s2_f16(self.h, _p(xb), n, hh, ww, c, _p(y)))
+        return _bits_f32(y, y.shape)
+
+    def op_detect(self, loc, conf, mask, proto):
+        n = loc.shape[0]
+        lb, cb, mb, pb = _f16_bits(loc), _f16_bits(conf), _f16_bits(mask), _f16_bits(proto)
+        self._chk(self.L.yh_op_detect(self.h, _p(lb), _p(cb), _p(mb), _p(pb), n))
+        self.n = n
