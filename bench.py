@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — YOLACT-550 frames/s on N MI355X (one process per GPU), plus the roofline of the
+dominant kernel and the CPU oracle timed on the host cores.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+yh_set_input_u8_device (device->device) + yh_evaluate (preprocess, 86 convs, FPN, protonet, heads,
+softmax/top-k/Fast-NMS/mask assembly), hipGraph-replayed. Frames shard across ranks (weak scaling,
+--batch frames per GPU per step); the only collective is the one-time RCCL broadcast of the weight
+blob from rank 0. PyTorch is plumbing here (device buffers, torch.distributed), not the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tiny-object-detection_amd"))
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16
+HBM_PEAK_GBS = 8000.0
+
+
+def shard_frames(total_frames, world_size, rank):
+    """Contiguous block partition of frame indices: returns (start, count)."""
+    base, rem = divmod(total_frames, world_size)
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+def dominant_kernel(prof):
+    """Groups per-launch hipEvent timings by kernel symbol; returns the symbol with most time."""
+    by = {}
+    for p in prof:
+        sym = p["name"].split(":")[0]
+        d = by.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        d["ms"] += p["ms"]; d["flops"] += p["flops"]; d["bytes"] += p["bytes"]; d["launches"] += 1
+    sym = max(by, key=lambda k: by[k]["ms"])
+    return sym, by
+
+
+def roofline_of(prof):
+    sym, by = dominant_kernel(prof)
+    d = by[sym]
+    total_ms = sum(p["ms"] for p in prof)
+    if d["flops"] > 0:
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        r = dict(bound="mfma", achieved=round(achieved, 2), peak=MFMA_F16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
+                 frac=round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), traffic=None)
+    else:
+        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        r = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None)
+    r.update(kernel=sym, launches=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 5),
+             share_of_step=round(d["ms"] / total_ms, 3), algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
+             algorithmic_gbytes_hbm=round(d["bytes"] / 1e9, 4),
+             hbm_gbs_algorithmic=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1))
+    return r
+
+
+def cpu_baseline(seed, frames_u8):
+    """The CPU oracle ("port": oracle/orc_net.c + orc_detect.c, the checker, never the product)
+    timed on this host's cores on ONE 550x550 frame of the same workload (118.3 GFLOP)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    cores = min(os.cpu_count() or 1, 16)
+    net = O.Net(50, frames_u8.shape[1], 81, seed=seed)
+    t0 = time.perf_counter()
+    loc, conf, mask, proto = net.forward(frames_u8[:1], f16=True, nthreads=cores)
+    O.detect(loc[0], conf[0], mask[0], proto[0], net.priors())
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 4), unit="frames/s", cores=cores, kind="port",
+                sample=f"1 frame {frames_u8.shape[1]}x{frames_u8.shape[2]}x3, full forward + detection tail, "
+                       f"f16-storage oracle (OpenMP, {cores} threads), {dt:.1f} s")
+
+
+def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4):
+    eng = ya.Engine(input_size=size, backbone=50, max_batch=batch, use_graph=True, device=local_rank)
+    eng.load_weights_device(blob_dev_ptr, blob_nbytes)
+    g = torch.Generator(device=f"cuda:{local_rank}")
+    start, _ = shard_frames(world * batch, world, rank)
+    g.manual_seed(0x594F4C41 + start)   # counter-based per-shard seed
+    bufs = [torch.randint(0, 256, (batch, size, size, 3), dtype=torch.uint8, device=f"cuda:{local_rank}", generator=g)
+            for _ in range(ring)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        eng.set_input_device(bufs[i % ring].data_ptr(), batch)
+        eng.evaluate()
+    for i in range(warmup):
+        step(i)
+    eng.sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(); eng.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    eng.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dt = float(t.item())
+    prof = eng.profile(with_tail=True, reps=3) if rank == 0 else None
+    ndet = sum(len(eng.detections(f, want_masks=False)[0]) for f in range(min(batch, 4))) if rank == 0 else 0
+    flops = eng.flops_per_frame()
+    host_frame = bufs[0][:1].cpu().numpy() if rank == 0 else None
+    eng.close()
+    return dt, prof, flops, ndet, host_frame
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (64: configs[2]/[3]; 1: configs[1])")
+    ap.add_argument("--size", type=int, default=550)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import yolact_amd as ya
+    rank, world, local_rank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernel library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    # weights: generated once on rank 0, replicated with ONE RCCL broadcast over xGMI
+    probe = ya.Engine(input_size=a.size, backbone=50, max_batch=1, use_graph=False, device=local_rank)
+    nbytes = probe.weights_nbytes()
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+    if rank == 0:
+        blob.copy_(torch.from_numpy(probe.generate_weights(a.seed)))
+    probe.close()
+    if dist is not None:
+        dist.broadcast(blob, src=0)
+    torch.cuda.synchronize()
+
+    dt, prof, flops, ndet, frame = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
+                                              a.seed, a.size, blob.data_ptr(), nbytes)
+    extra = {}
+    if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
+        s1 = max(a.steps * 4, 40)
+        dt1, prof1, _, _, _ = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
+                                         blob.data_ptr(), nbytes)
+        if rank == 0:
+            extra["batch1"] = dict(workload=f"YOLACT-550 R50-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
+                                   value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
+                                   net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1))
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    fps = world * a.batch * a.steps / dt
+    line = {
+        "metric": "frames/sec YOLACT-550 (ResNet-50-FPN, 32 prototypes) fp16, forward + detection tail",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"YOLACT-550 R50-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, "
+                               f"hipGraph steady state, frames sharded over {world} GPU(s), weights replicated by one RCCL broadcast",
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [a.size, a.size, 3],
+                   "weights": f"seeded synthetic (seed {a.seed}), BN folded", "detections_first_frames": ndet},
+        "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
+        "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),
+        "roofline": roofline_of(prof),
+    }
+    line.update(extra)
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(a.seed, frame)
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

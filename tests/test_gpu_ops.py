@@ -1,0 +1,86 @@
+"""-m gpu: single HIP kernels through the C ABI vs the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def f16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def eng(built):
+    import yolact_amd as ya
+    e = ya.Engine(input_size=128, max_batch=2, use_graph=False)
+    yield e
+    e.close()
+
+
+def test_mfma_operand_and_output_maps(eng, oracle):
+    """A = I with an ASYMMETRIC B: a 1x1 conv whose weight is the identity must copy x exactly,
+    and a weight with one 1 per row at a shifted column must permute channels: catches swapped
+    row/col or k-order maps of v_mfma_f32_32x32x16_f16."""
+    rng = np.random.default_rng(1)
+    c = 128
+    x = f16(rng.integers(-8, 9, (1, 5, 7, c)))
+    w = np.zeros((c, 1, 1, c), np.float32)
+    w[np.arange(c), 0, 0, (np.arange(c) * 37 + 11) % c] = 1.0
+    y = eng.op_conv2d(x, w, np.zeros(c, np.float32))
+    assert np.array_equal(y, x[..., (np.arange(c) * 37 + 11) % c])
+
+
+CASES = [  # n, h, w, cin, cout, k, stride, pad, res, act
+    (1, 8, 8, 64, 128, 1, 1, 0, False, 0),
+    (1, 9, 7, 64, 64, 3, 1, 1, False, 1),
+    (2, 17, 13, 128, 256, 3, 2, 1, True, 1),
+    (1, 20, 20, 256, 32, 1, 1, 0, False, 1),
+    (1, 12, 12, 256, 351, 3, 1, 1, False, 2),
+    (1, 33, 31, 3, 64, 7, 2, 3, False, 1),
+    (2, 16, 16, 256, 256, 3, 1, 1, False, 1),
+    (1, 5, 5, 256, 256, 3, 2, 1, False, 0),      # FPN downsample on a 5x5 map
+    (3, 1, 1, 256, 351, 3, 1, 1, False, 2),      # 1x1 spatial, all taps but the centre padded
+    (1, 35, 35, 512, 128, 1, 2, 0, False, 0),    # strided 1x1 projection
+    (1, 18, 18, 2048, 256, 1, 1, 0, True, 0),    # deep K
+    (1, 40, 40, 64, 12, 3, 1, 1, False, 0),      # tiny cout
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,act", CASES)
+def test_conv_vs_oracle(eng, oracle, n, h, w, cin, cout, k, stride, pad, res, act):
+    rng = np.random.default_rng(n * 7 + cin + cout)
+    x = f16(rng.normal(0, 1, (n, h, w, cin)))
+    wt = f16(rng.normal(0, 1, (cout, k, k, cin)) / np.sqrt(k * k * cin))
+    b = rng.normal(0, 0.1, cout).astype(np.float32)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = f16(rng.normal(0, 1, (n, ho, wo, cout))) if res else None
+    y = eng.op_conv2d(x, wt, b, stride, pad, r, act)
+    yo = oracle.conv2d(x, wt, b, stride, pad, r, act, f16=True)
+    # f32 accumulate on both sides; only summation order differs -> at most 1 f16 ulp apart
+    tol = 2.0 ** -10 * np.maximum(np.abs(yo), 1.0) + 1e-3
+    assert (np.abs(y - yo) <= tol).all(), float(np.abs(y - yo).max())
+
+
+def test_conv_exact_on_integers(eng, oracle):
+    """Small-integer data: every product and partial sum is exact in f32, so any summation order
+    gives the same bits; the kernel must match the oracle bit for bit (indexing, padding, bias)."""
+    rng = np.random.default_rng(9)
+    x = rng.integers(-3, 4, (2, 11, 9, 64)).astype(np.float32)
+    wt = rng.integers(-2, 3, (128, 3, 3, 64)).astype(np.float32)
+    b = rng.integers(-4, 5, 128).astype(np.float32)
+    r = rng.integers(-5, 6, (2, 11, 9, 128)).astype(np.float32)
+    y = eng.op_conv2d(x, wt, b, 1, 1, r, 1)
+    yo = oracle.conv2d(x, wt, b, 1, 1, r, 1, f16=True)
+    assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
+def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
+    x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))
+    assert np.array_equal(eng.op_bilinear(x, ho, wo), oracle.bilinear(x, ho, wo, f16=True))
+
+
+@pytest.mark.parametrize("h,w", [(275, 9), (12, 12), (7, 9), (1, 1)])
+def test_maxpool_bit_exact(eng, oracle, h, w):
+    x = f16(np.random.default_rng(w).normal(0, 2, (2, h, w, 64)))
+    assert np.array_equal(eng.op_maxpool(x), oracle.maxpool3x3s2(x))
