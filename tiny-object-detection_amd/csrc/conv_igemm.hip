@@ -3,18 +3,20 @@
 // Replaces, for the YOLACT path, the CONV_2D / ADD / PAD / RELU / TANH ops that the reference
 // executes inside interpreter.invoke() (/root/reference/src/yolact.rs:163; op histogram
 // data/FRC_model_edgetpu.log:7-19): bias, residual add, ReLU and tanh are fused in the epilogue,
-// zero padding is the buffer-descriptor bounds check of the activation loads.
+// zero padding is folded into the loader (no PAD op, no padded copies).
 //
 //   D[ch][m] = sum_k Wt[ch][k] * X[m][k]     (weights are the MFMA A operand, activations B)
 //
 // Work decomposition: one 256-thread workgroup (4 waves, one per SIMD) owns a TCH x TM output
 // tile; each wave owns (TCH/WCH) x (TM/WM) of it as 32x32 v_mfma_f32_32x32x16_f16 tiles with f32
-// accumulators. K advances 64 at a time (one 128-byte row segment per tile row): global ->
-// registers (16 B per lane, 8 lanes per 128-B line) -> LDS, double buffered, one barrier per step,
-// the loads of step k+1 issued before the MFMAs of step k (register staging, T14 order).
-// LDS rows are 128 B; 16-byte chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)), which makes
-// both the ds_write_b128 staging stores and the ds_read_b128 fragment reads conflict free
-// (bank row = 256 B = two LDS rows).
+// accumulators. K advances 64 at a time (one 128-byte row segment per tile row): global -> LDS
+// directly by LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane, 8 lanes per 128-B line, no VGPR
+// staging, no ds_write), double buffered, one barrier per step, the DMA of step k+1 in flight
+// under the MFMAs of step k. LDS rows are 128 B; logical 16-byte chunk c of row r lives at physical
+// chunk (c ^ ((r >> 1) & 7)): the DMA image is lane-linear, so the permutation is applied to each
+// lane's SOURCE address, and the same XOR on the ds_read_b128 fragment reads makes them conflict
+// free (bank row = 256 B = two LDS rows). Zero padding: out-of-image taps read a 16-byte zero
+// block kept at the end of every activation allocation (inside the descriptor's range).
 // Epilogue: accumulators -> LDS as f32 [m][ch] (lane holds 4 consecutive channels per register
 // quad), then whole 16-byte f16 channel groups are written with coalesced row stores.
 #include "yh_internal.h"
@@ -50,7 +52,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
     const int tid = threadIdx.x, chunk = tid & 7, rb = tid >> 3;
     const int PQ = p.P * p.Q;
 
-    // ---- per-thread staging rows of the activation tile
+    // ---- per-thread staging rows of the activation tile.
+    // LDS-DMA (buffer_load ... lds) writes wave-uniform base + lane*16: thread tid always fills
+    // physical 16-byte chunk (tid & 7) of row (tid >> 3) + 32 i, so the XOR swizzle moves to the
+    // SOURCE side: it fetches logical chunk lc = (tid & 7) ^ ((row >> 1) & 7).
+    const int lc = chunk ^ ((rb >> 1) & 7);
     int xbase[XL], xih[XL], xiw[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
             const int op = rem / p.Q, oq = rem - op * p.Q;
             xih[i] = op * p.stride - p.pad;
             xiw[i] = oq * p.stride - p.pad;
-            xbase[i] = (int)(n * p.x_img_stride) + (xih[i] * p.W + xiw[i]) * p.C + (SMALLC ? 0 : chunk * 8);
+            xbase[i] = (int)(n * p.x_img_stride) + (xih[i] * p.W + xiw[i]) * p.C + (SMALLC ? 0 : lc * 8);
         } else {
             xih[i] = -(1 << 24);
             xiw[i] = 0;
@@ -69,45 +75,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
     }
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const half_t* wptr = p.w + (size_t)(ch_tile * TCH + rb) * p.ldw + chunk * 8;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const unsigned wbase = (unsigned)(((ch_tile * TCH + rb) * p.ldw + lc * 8) * 2);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds3 = (lds_char*)lds;
 
     // position of the NEXT tile to load along K
     int kr = 0, ks = 0, kc = 0, kt_load = 0;
-    u32x4 xr[XL], wr[WL];
 
-    auto load_tile = [&]() {
+    auto load_tile = [&](int buf) {
         int r, s, rs_off;
         if (SMALLC) {
-            const int2 tap = p.rs_table[kt_load * 8 + chunk];
+            const int2 tap = p.rs_table[kt_load * 8 + lc];
             r = tap.x; s = tap.y;
             rs_off = (r * p.W + s) * 8;
         } else {
             r = kr; s = ks;
             rs_off = (kr * p.W + ks) * p.C + kc;
         }
+        lds_char* const dstw = lds3 + buf * AB_BYTES + wave * 1024;
+        lds_char* const dstx = dstw + TCH * 128;
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + i * 4096, 16,
+                                                     (int)(wbase + (unsigned)((32 * i) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             const bool ok = (unsigned)(xih[i] + r) < (unsigned)p.H && (unsigned)(xiw[i] + s) < (unsigned)p.W;
-            const unsigned voff = ok ? (unsigned)(xbase[i] + rs_off) * 2u : p.x_bytes;
-            xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+            // padded taps read the 16-byte zero block that ends every activation allocation
+            const unsigned voff = ok ? (unsigned)(xbase[i] + rs_off) * 2u : p.x_zero_off;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstx + i * 4096, 16, (int)voff, 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < WL; ++i)
-            wr[i] = *(const u32x4*)(wptr + (size_t)(32 * i) * p.ldw + kt_load * 64);
         ++kt_load;
         if (!SMALLC) {
             kc += 64;
             if (kc >= p.C) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
         }
-    };
-    // swizzled LDS byte offset of (row rb + 32 i, chunk): the XOR term is constant per thread
-    const int st_off = rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
-    auto store_tile = [&](int buf) {
-        char* base = lds + buf * AB_BYTES;
-#pragma unroll
-        for (int i = 0; i < WL; ++i) *(u32x4*)(base + st_off + i * 4096) = wr[i];
-#pragma unroll
-        for (int i = 0; i < XL; ++i) *(u32x4*)(base + TCH * 128 + st_off + i * 4096) = xr[i];
     };
 
     const int lane = tid & 63, wid = tid >> 6;
@@ -123,14 +128,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_tile();
-    store_tile(0);
-    __syncthreads();
+    load_tile(0);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
 
     int cur = 0;
     for (int kt = 0; kt < p.ksteps; ++kt) {
-        const bool more = kt + 1 < p.ksteps;
-        if (more) load_tile();
+        if (kt + 1 < p.ksteps) load_tile(cur ^ 1);  // DMA of step k+1 flies under the MFMAs of step k
         const char* base = lds + cur * AB_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -146,8 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
                 for (int j = 0; j < TMT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
+        __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
         cur ^= 1;
     }
 
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
         }
     __syncthreads();
 
-    constexpr int TPR = TCH / 8, RPP = 256 / TPR;
+    constexpr int TPR = TCH / 8, RPP = 256 / TPR, NPASS = TM / RPP;
     const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
     const int ch = ch_tile * TCH + ch_l;
     if (ch >= p.cout8) return;
@@ -177,15 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
-#pragma unroll 2
-    for (int pass = 0; pass < TM / RPP; ++pass) {
-        const int m_l = pass * RPP + rr, m = m_tile * TM + m_l;
-        if (m >= p.M) break;
-        const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-        long long yo, ro;
+    auto offsets = [&](int m, long long& yo, long long& ro) {
         if (p.y_dense) {
             yo = (long long)m * p.ldy + ch;
             ro = (long long)m * p.ldres + ch;
@@ -194,24 +188,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
             yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
             ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
         }
-        if (p.res) {
-            const half8 rv = *(const half8*)(p.res + ro);
+    };
+    // all residual rows of this thread are requested up front (one latency, not NPASS of them)
+    half8 rv[NPASS];
+    if (p.res) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int m = m_tile * TM + pass * RPP + rr;
+            long long yo, ro;
+            offsets(m < p.M ? m : 0, yo, ro);
+            rv[pass] = *(const half8*)(p.res + ro);
         }
-        if (p.act == 1) {
+    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int m_l = pass * RPP + rr, m = m_tile * TM + m_l;
+        if (m < p.M) {
+            const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+            long long yo, ro;
+            offsets(m, yo, ro);
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+            if (ch + 8 > p.tanh_from) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            *(half8*)(p.y + yo) = o;
         }
-        if (ch + 8 > p.tanh_from) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
-        }
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-        *(half8*)(p.y + yo) = o;
     }
 }
 

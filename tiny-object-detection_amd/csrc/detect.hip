@@ -22,19 +22,41 @@
 namespace yh {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define YH_DETS_MAX_K3 128
 
-__global__ __launch_bounds__(256) void det_softmax_cand(const DetectParams p) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)p.n * p.P) return;
-    const int b = (int)(t / p.P), pr = (int)(t % p.P);
-    const int cell = pr / 3, a = pr - cell * 3, C = p.C;
-    const half_t* z = p.heads + ((long long)b * p.cells + cell) * p.ldh + 12 + a * C;
-    float m = (float)z[0];
-    for (int c = 1; c < C; ++c) { const float v = (float)z[c]; m = v > m ? v : m; }
+// K1: one workgroup = 64 consecutive head rows (cells) = 192 priors, one lane per prior.
+// Rows are fetched whole with 16-byte coalesced loads and their conf part scattered to LDS as f32
+// at [prior_local*C + c] (odd stride: conflict-free lane-per-prior reads). Pass 1 max, pass 2
+// exp + sequential sum (exp values parked in LDS), pass 3 divide + threshold + append.
+#define YH_K1_ROWS 64
+__global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [192][C]
+    const int C = p.C, tid = threadIdx.x;
+    const long long rows = (long long)p.n * p.cells;
+    const long long r0 = (long long)blockIdx.x * YH_K1_ROWS;
+    const int chunks = p.ldh / 8;  // 16-byte chunks per row
+    for (int i = tid; i < YH_K1_ROWS * chunks; i += 192) {
+        const int rl = i / chunks, j = i - rl * chunks;
+        if (r0 + rl >= rows) continue;
+        const half8 v = *(const half8*)(p.heads + (r0 + rl) * p.ldh + j * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = j * 8 + e - 12;
+            if (q >= 0 && q < 3 * C) zs[rl * 3 * C + q] = (float)v[e];
+        }
+    }
+    __syncthreads();
+    const long long row = r0 + tid / 3;
+    if (row >= rows) return;
+    const int b = (int)(row / p.cells), cell = (int)(row - (long long)b * p.cells);
+    const int pr = cell * 3 + tid % 3;
+    float* z = zs + tid * C;
+    float m = z[0];
+    for (int c = 1; c < C; ++c) { const float v = z[c]; m = v > m ? v : m; }
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s = __fadd_rn(s, spec_expf(__fsub_rn((float)z[c], m)));
+    for (int c = 0; c < C; ++c) { const float e = spec_expf(__fsub_rn(z[c], m)); z[c] = e; s = __fadd_rn(s, e); }
     for (int c = 1; c < C; ++c) {
-        const float pc = __fdiv_rn(spec_expf(__fsub_rn((float)z[c], m)), s);
+        const float pc = __fdiv_rn(z[c], s);
         if (pc > p.conf_thresh) {
             const int list = b * (C - 1) + (c - 1);
             const int slot = atomicAdd(&p.cls_count[list], 1);
@@ -55,33 +77,99 @@ __device__ __forceinline__ float box_iou(const float4 a, const float4 b) {
     return uni > 0.0f ? __fdiv_rn(inter, uni) : 0.0f;
 }
 
-#define YH_TOPK_MAX 256
+// Exact k-th largest of n UNIQUE 64-bit keys by MSB-first radix select: 8 passes of a 256-bin LDS
+// histogram over the keys that still match the prefix; the bin holding the k-th key is found by one
+// wave (4 bins per lane + a suffix scan by shuffles). Every thread of the workgroup must call it.
+template <int NT, class KeyFn>
+__device__ unsigned long long radix_select_kth(KeyFn key_of, int n, int k, int* hist, int* sh) {
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0, mask = 0;
+    int kk = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += NT) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const unsigned long long key = key_of(i);
+            if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int incl = mine;  // inclusive suffix sum over lanes >= tid
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_down(incl, d);
+                incl += (tid + d < 64) ? o : 0;
+            }
+            const int above = incl - mine;
+            if (above < kk && kk <= incl) {  // exactly one lane
+                int c = above, bsel;
+                if (c + h3 >= kk) bsel = 3;
+                else { c += h3; if (c + h2 >= kk) bsel = 2; else { c += h2; if (c + h1 >= kk) bsel = 1; else { c += h1; bsel = 0; } } }
+                sh[0] = 4 * tid + bsel;
+                sh[1] = kk - c;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)(unsigned)sh[0] << shift;
+        mask |= 0xFFull << shift;
+        kk = sh[1];
+        __syncthreads();
+    }
+    return prefix;
+}
 
+#define YH_TOPK_MAX 256
+#define YH_K2_STAGE 4096
+
+// K2: one workgroup per (frame, class).
 __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
-    __shared__ float sel_score[YH_TOPK_MAX];
-    __shared__ int sel_prior[YH_TOPK_MAX];
+    __shared__ unsigned long long stage[YH_K2_STAGE];   // candidate keys (when they fit)
+    __shared__ unsigned long long sel[YH_TOPK_MAX];     // the K selected keys, then sorted
+    __shared__ unsigned long long sorted[YH_TOPK_MAX];
     __shared__ float4 sel_box[YH_TOPK_MAX];
+    __shared__ int hist[256];
+    __shared__ int sh[4];
     const int list = blockIdx.x;  // b*(C-1) + c
     const int b = list / (p.C - 1);
     const int tid = threadIdx.x;
     const int nc = p.cls_count[list];
     const uint2* cand = p.cand + (long long)list * p.P;
     const int K = nc < p.top_k ? nc : p.top_k;
-    // rank-by-counting: keys are unique (prior breaks score ties), so ranks are a permutation
+    const long long so = (long long)list * p.top_k;
+    if (nc == 0) {  // uniform
+        for (int j = tid; j < p.top_k; j += 256) p.surv_score[so + j] = -1.0f;
+        return;
+    }
+    // key = score bits (positive float: monotone) : ~prior  -> larger key = better, keys unique
+    const bool staged = nc <= YH_K2_STAGE;
+    if (staged) {
+        for (int i = tid; i < nc; i += 256) { const uint2 c = cand[i]; stage[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y); }
+    }
+    if (tid == 0) sh[2] = 0;
+    __syncthreads();
+    auto key_of = [&](int i) -> unsigned long long {
+        if (staged) return stage[i];
+        const uint2 c = cand[i];
+        return ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
+    };
+    unsigned long long T = 0;
+    if (nc > p.top_k) T = radix_select_kth<256>(key_of, nc, K, hist, sh);
     for (int i = tid; i < nc; i += 256) {
-        const uint2 me = cand[i];
-        const float si = __uint_as_float(me.x);
+        const unsigned long long key = key_of(i);
+        if (key >= T) sel[atomicAdd(&sh[2], 1)] = key;  // exactly K keys pass
+    }
+    __syncthreads();
+    if (tid < K) {  // order the K selected keys by counting
+        const unsigned long long me = sel[tid];
         int rank = 0;
-        for (int j = 0; j < nc; ++j) {
-            const uint2 o = cand[j];  // uniform address: one broadcast load per wave
-            const float sj = __uint_as_float(o.x);
-            rank += (sj > si || (sj == si && o.y < me.y)) ? 1 : 0;
-        }
-        if (rank < p.top_k) { sel_score[rank] = si; sel_prior[rank] = (int)me.y; }
+        for (int j = 0; j < K; ++j) rank += sel[j] > me ? 1 : 0;
+        sorted[rank] = me;
     }
     __syncthreads();
     if (tid < K) {
-        const int pr = sel_prior[tid], cell = pr / 3, a = pr - cell * 3;
+        const int pr = (int)(0xFFFFFFFFu - (unsigned)(sorted[tid] & 0xFFFFFFFFull)), cell = pr / 3, a = pr - cell * 3;
         const half_t* l = p.heads + ((long long)b * p.cells + cell) * p.ldh + a * 4;
         const float4 q = *(const float4*)(p.priors + (long long)pr * 4);
         const float l0 = (float)l[0], l1 = (float)l[1], l2 = (float)l[2], l3 = (float)l[3];
@@ -97,7 +185,6 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
         sel_box[tid] = bx;
     }
     __syncthreads();
-    const long long so = (long long)list * p.top_k;
     for (int j = tid; j < p.top_k; j += 256) {
         float out = -1.0f;
         if (j < K) {
@@ -105,8 +192,8 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
             bool keep = true;
             for (int i = 0; i < j; ++i) keep = keep && !(box_iou(sel_box[i], bj) > p.nms_thresh);
             if (keep) {
-                out = sel_score[j];
-                p.surv_prior[so + j] = sel_prior[j];
+                out = __uint_as_float((unsigned)(sorted[j] >> 32));
+                p.surv_prior[so + j] = (int)(0xFFFFFFFFu - (unsigned)(sorted[j] & 0xFFFFFFFFull));
                 *(float4*)(p.surv_box + (so + j) * 4) = bj;
             }
         }
@@ -116,51 +203,55 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
 
 #define YH_SLOTS_MAX 16384
 
+// K3: one workgroup per frame: survivors -> exact top max_dets in (score desc, slot asc) order.
 __global__ __launch_bounds__(1024) void det_frame_top(const DetectParams p) {
-    __shared__ float vs[YH_SLOTS_MAX];
-    __shared__ int vi[YH_SLOTS_MAX];
-    __shared__ int V;
+    __shared__ unsigned long long keys[YH_SLOTS_MAX];
+    __shared__ unsigned long long sel[YH_DETS_MAX_K3];
+    __shared__ int hist[256];
+    __shared__ int sh[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NS = (p.C - 1) * p.top_k;
-    if (tid == 0) V = 0;
+    if (tid == 0) { sh[2] = 0; sh[3] = 0; }
     __syncthreads();
     const float* ss = p.surv_score + (long long)b * NS;
     for (int i = tid; i < NS; i += 1024) {
         const float s = ss[i];
-        if (s >= 0.0f) { const int pos = atomicAdd(&V, 1); vs[pos] = s; vi[pos] = i; }
+        if (s >= 0.0f) keys[atomicAdd(&sh[2], 1)] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
     }
     __syncthreads();
-    const int nv = V;
-    for (int e = tid; e < nv; e += 1024) {
-        const float se = vs[e];
-        const int ie = vi[e];
+    const int nv = sh[2];
+    const int K = nv < p.max_dets ? nv : p.max_dets;
+    if (tid == 0) p.det_count[b] = K;
+    if (nv == 0) return;
+    unsigned long long T = 0;
+    if (nv > p.max_dets) T = radix_select_kth<1024>([&](int i) { return keys[i]; }, nv, K, hist, sh);
+    for (int i = tid; i < nv; i += 1024)
+        if (keys[i] >= T) sel[atomicAdd(&sh[3], 1)] = keys[i];
+    __syncthreads();
+    if (tid < K) {
+        const unsigned long long me = sel[tid];
         int rank = 0;
-        for (int f = 0; f < nv; ++f) {
-            const float sf = vs[f];
-            rank += (sf > se || (sf == se && vi[f] < ie)) ? 1 : 0;
-        }
-        if (rank < p.max_dets) {
-            const long long slot = (long long)b * NS + ie;
-            yh_detection d;
-            d.class_id = ie / p.top_k;
-            d.prior = p.surv_prior[slot];
-            d.score = se;
-            const float4 bx = *(const float4*)(p.surv_box + slot * 4);
-            d.box[0] = bx.x; d.box[1] = bx.y; d.box[2] = bx.z; d.box[3] = bx.w;
-            p.dets[(long long)b * p.max_dets + rank] = d;
-            const float fw = (float)p.wp, fh = (float)p.hp;
-            const float x1 = __fmul_rn(bx.x, fw), x2 = __fmul_rn(bx.z, fw);
-            const float y1 = __fmul_rn(bx.y, fh), y2 = __fmul_rn(bx.w, fh);
-            float xa = __fsub_rn(fminf(x1, x2), 1.0f), xb = __fadd_rn(fmaxf(x1, x2), 1.0f);
-            float ya = __fsub_rn(fminf(y1, y2), 1.0f), yb = __fadd_rn(fmaxf(y1, y2), 1.0f);
-            xa = xa < 0.0f ? 0.0f : xa;
-            ya = ya < 0.0f ? 0.0f : ya;
-            xb = xb > fw ? fw : xb;
-            yb = yb > fh ? fh : yb;
-            *(float4*)(p.det_crop + ((long long)b * p.max_dets + rank) * 4) = make_float4(xa, xb, ya, yb);
-        }
+        for (int j = 0; j < K; ++j) rank += sel[j] > me ? 1 : 0;
+        const int ie = (int)(0xFFFFFFFFu - (unsigned)(me & 0xFFFFFFFFull));
+        const long long slot = (long long)b * NS + ie;
+        yh_detection d;
+        d.class_id = ie / p.top_k;
+        d.prior = p.surv_prior[slot];
+        d.score = __uint_as_float((unsigned)(me >> 32));
+        const float4 bx = *(const float4*)(p.surv_box + slot * 4);
+        d.box[0] = bx.x; d.box[1] = bx.y; d.box[2] = bx.z; d.box[3] = bx.w;
+        p.dets[(long long)b * p.max_dets + rank] = d;
+        const float fw = (float)p.wp, fh = (float)p.hp;
+        const float x1 = __fmul_rn(bx.x, fw), x2 = __fmul_rn(bx.z, fw);
+        const float y1 = __fmul_rn(bx.y, fh), y2 = __fmul_rn(bx.w, fh);
+        float xa = __fsub_rn(fminf(x1, x2), 1.0f), xb = __fadd_rn(fmaxf(x1, x2), 1.0f);
+        float ya = __fsub_rn(fminf(y1, y2), 1.0f), yb = __fadd_rn(fmaxf(y1, y2), 1.0f);
+        xa = xa < 0.0f ? 0.0f : xa;
+        ya = ya < 0.0f ? 0.0f : ya;
+        xb = xb > fw ? fw : xb;
+        yb = yb > fh ? fh : yb;
+        *(float4*)(p.det_crop + ((long long)b * p.max_dets + rank) * 4) = make_float4(xa, xb, ya, yb);
     }
-    if (tid == 0) p.det_count[b] = nv < p.max_dets ? nv : p.max_dets;
 }
 
 #define YH_DETS_MAX 128
@@ -214,8 +305,9 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
     switch (stage) {
         case 0: return hipMemsetAsync(p.cls_count, 0, sizeof(int) * (size_t)p.n * (p.C - 1), s);
         case 1: {
-            const long long np = (long long)p.n * p.P;
-            hipLaunchKernelGGL(det_softmax_cand, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, p);
+            const long long rows = (long long)p.n * p.cells;
+            hipLaunchKernelGGL(det_softmax_cand, dim3((unsigned)((rows + YH_K1_ROWS - 1) / YH_K1_ROWS)), dim3(192),
+                               (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }
         case 2: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;

@@ -43,6 +43,7 @@ struct Buf {               // dense NHWC f16 tensor [max_batch][h][w][c] or a sl
     half_t* d = nullptr;
     int h = 0, w = 0, c = 0;       // c = row stride in elements
     long long img_stride = 0;      // elements per image
+    half_t* zero = nullptr;        // 16-byte zero block at the end of the owning allocation
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_BILINEAR };
@@ -149,9 +150,12 @@ int new_buf(yh_engine* h, const char* name, int hh, int ww, int c, Buf* out) {
     b.h = hh; b.w = ww; b.c = c;
     b.img_stride = (long long)hh * ww * c;
     void* p = nullptr;
-    int rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * b.img_stride * 2);
+    const size_t data_bytes = (size_t)h->cfg.max_batch * b.img_stride * 2;
+    int rc = dev_alloc(h, &p, data_bytes + 256);
     if (rc) return rc;
+    if (hipMemset(p, 0, data_bytes + 256) != hipSuccess) return h->fail(YH_EHIP, "hipMemset arena");
     b.d = (half_t*)p;
+    b.zero = (half_t*)((char*)p + ((data_bytes + 15) & ~(size_t)15));
     if (name) h->named[name] = b;
     *out = b;
     return YH_OK;
@@ -430,9 +434,11 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     p.res = o.has_res ? o.res.d : nullptr;
     p.x_img_stride = o.in.img_stride; p.y_img_stride = o.out.img_stride;
     p.res_img_stride = o.has_res ? o.res.img_stride : 0;
-    const long long xb = ((long long)(n - 1) * o.in.img_stride + (long long)o.in.h * o.in.w * o.in.c) * 2;
-    if (xb >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
-    p.x_bytes = (unsigned)xb;
+    const long long zo = (const char*)o.in.zero - (const char*)o.in.d;
+    if (zo < 0 || zo >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+    p.x_zero_off = (unsigned)zo;
+    p.x_bytes = (unsigned)zo + 16u;
+    p.w_bytes = (unsigned)((size_t)pn.coutPad * pn.Kpad * 2);
     p.N = n; p.H = o.in.h; p.W = o.in.w; p.C = pn.cin_store;
     p.P = o.P; p.Q = o.Q; p.R = pn.k; p.S = pn.k; p.stride = o.stride; p.pad = o.pad;
     p.M = n * o.P * o.Q;
@@ -1027,7 +1033,8 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     std::vector<int2> tab;
     if (cin == 3) { tab.resize(Kpad / 8); for (int i = 0; i < Kpad / 8; ++i) tab[i] = i < k * k ? make_int2(i / k, i % k) : make_int2(1 << 20, 0); }
     void *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dr = nullptr, *dt = nullptr;
-    hipError_t e = hipMalloc(&dx, xs.size() * 2);
+    hipError_t e = hipMalloc(&dx, xs.size() * 2 + 64);
+    if (e == hipSuccess) e = hipMemset(dx, 0, xs.size() * 2 + 64);
     if (e == hipSuccess) e = hipMalloc(&dw, wp.size() * 2);
     if (e == hipSuccess) e = hipMalloc(&db, bp.size() * 4);
     if (e == hipSuccess) e = hipMalloc(&dy, ys.size() * 2);
@@ -1045,7 +1052,9 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
         p.x = (const half_t*)dx; p.w = (const half_t*)dw; p.bias = (const float*)db; p.res = (const half_t*)dr; p.y = (half_t*)dy;
         p.rs_table = (const int2*)dt;
         p.x_img_stride = (long long)hh * ww * cs; p.y_img_stride = (long long)P * Q * cout8; p.res_img_stride = p.y_img_stride;
-        p.x_bytes = (unsigned)(xs.size() * 2);
+        p.x_zero_off = (unsigned)((xs.size() * 2 + 15) & ~(size_t)15);
+        p.x_bytes = p.x_zero_off + 16u;
+        p.w_bytes = (unsigned)(wp.size() * 2);
         p.N = n; p.H = hh; p.W = ww; p.C = cs; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
         p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad; p.ksteps = Kpad / 64; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
         p.act = act == 1 ? 1 : 0; p.tanh_from = act == 2 ? 0 : INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile);

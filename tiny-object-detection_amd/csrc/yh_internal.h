@@ -26,7 +26,9 @@ struct ConvParams {
     half_t* y;            // output base
     const int2* rs_table; // small-C mode: (r, s) per 16-byte chunk index; r = 1<<20 marks padding
     long long x_img_stride, y_img_stride, res_img_stride; // elements per image
-    unsigned x_bytes;     // bytes addressable from x (buffer bounds: taps outside read 0)
+    unsigned x_bytes;     // bytes addressable from x (buffer descriptor range, includes the zero block)
+    unsigned x_zero_off;  // byte offset from x of a 16-byte block of zeros (padded taps read it)
+    unsigned w_bytes;     // bytes of the weight panel
     int N, H, W, C;       // input
     int P, Q;             // output spatial
     int R, S, stride, pad;
