@@ -31,15 +31,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int A, int B>
 struct cmax { static constexpr int v = A > B ? A : B; };
 
-template <int TCH, int TM, int WCH, int WM, bool SMALLC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
+// STAGES == 2: double buffer, __syncthreads() per step (drains the DMA: vmcnt(0)).
+// STAGES == 3: ring of three; the DMA of step k+2 is issued while step k computes, each step waits
+//              only for ITS tile with a counted s_waitcnt vmcnt(N) (N = this wave's DMA instructions
+//              per tile) and a raw s_barrier, so one tile stays in flight across every barrier.
+// EPI: the epilogue's f32 staging image covers TM / EPI rows at a time (a 256 x 256 tile's does not
+//      fit in LDS at once).
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI>
+__global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
+    constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
     constexpr int TC = WTC / 32, TMT = WTM / 32;   // MFMA tiles per wave
-    constexpr int XL = TM / 32, WL = TCH / 32;     // 16-byte staging loads per thread
+    constexpr int XL = TM / RSTEP, WL = TCH / RSTEP;  // LDS-DMA instructions per thread per tile
     constexpr int AB_BYTES = (TCH + TM) * 128;
     constexpr int ES = TCH + 4;                    // epilogue row stride in floats
-    constexpr int LDS_BYTES = cmax<2 * AB_BYTES, TM * ES * 4>::v;
-    static_assert(WCH * WM == 4 && WTC % 32 == 0 && WTM % 32 == 0, "4 waves, 32x32 tiles");
+    constexpr int LDS_BYTES = cmax<STAGES * AB_BYTES, (TM / EPI) * ES * 4>::v;
+    static_assert(WM % EPI == 0, "epilogue split");
+    static_assert((NW == 4 || NW == 8) && WTC % 32 == 0 && WTM % 32 == 0 && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
+    static_assert(STAGES == 2 || (STAGES == 3 && !SMALLC), "3-stage ring: no ordinary loads may share the loop");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
     // XCD-aware bijective remap: consecutive work ids (which share activation rows / weight
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
     int xbase[XL], xih[XL], xiw[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        const int m = m_tile * TM + rb + 32 * i;
+        const int m = m_tile * TM + rb + RSTEP * i;
         if (m < p.M) {
             const int n = m / PQ, rem = m - n * PQ;
             const int op = rem / p.Q, oq = rem - op * p.Q;
@@ -99,14 +109,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
         lds_char* const dstx = dstw + TCH * 128;
 #pragma unroll
         for (int i = 0; i < WL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + i * 4096, 16,
-                                                     (int)(wbase + (unsigned)((32 * i) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + i * (RSTEP * 128), 16,
+                                                     (int)(wbase + (unsigned)((RSTEP * i) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             const bool ok = (unsigned)(xih[i] + r) < (unsigned)p.H && (unsigned)(xiw[i] + s) < (unsigned)p.W;
             // padded taps read the 16-byte zero block that ends every activation allocation
             const unsigned voff = ok ? (unsigned)(xbase[i] + rs_off) * 2u : p.x_zero_off;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstx + i * 4096, 16, (int)voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstx + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
         }
         ++kt_load;
         if (!SMALLC) {
@@ -128,13 +138,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_tile(0);
-    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
-
-    int cur = 0;
-    for (int kt = 0; kt < p.ksteps; ++kt) {
-        if (kt + 1 < p.ksteps) load_tile(cur ^ 1);  // DMA of step k+1 flies under the MFMAs of step k
-        const char* base = lds + cur * AB_BYTES;
+    auto compute = [&](int buf) {
+        const char* base = lds + buf * AB_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co = ((2 * kk + lh) ^ swz) << 4;
@@ -149,33 +154,94 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
                 for (int j = 0; j < TMT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
-        cur ^= 1;
+    };
+
+    if (STAGES == 2) {
+        load_tile(0);
+        __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
+        int cur = 0;
+        for (int kt = 0; kt < p.ksteps; ++kt) {
+            if (kt + 1 < p.ksteps) load_tile(cur ^ 1);  // DMA of step k+1 flies under the MFMAs of step k
+            compute(cur);
+            __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
+            cur ^= 1;
+        }
+    } else {
+        // 3-stage ring + register double buffering of the MFMA fragments:
+        //   step k:  wait(tile k+1 landed) ; lgkmcnt(0) ; barrier ; DMA tile k+3 -> stage of tile k ;
+        //            ds_read all fragments of tile k+1 -> Rnext ; 16 MFMAs on Rcur (tile k)
+        // so the MFMAs of a step never wait on LDS latency (their operands were read one step
+        // earlier) and every DMA has two steps to land. Stage k is free for refill after the
+        // barrier because every wave drained its reads of tile k (lgkmcnt(0)) before arriving.
+        constexpr int NDMA = XL + WL;  // this wave's DMA instructions per tile
+        struct Frag { half8 a[4][TC], b[4][TMT]; };
+        auto read_frags = [&](int buf, Frag& f) {
+            const char* base = lds + buf * AB_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((2 * kk + lh) ^ swz) << 4;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) f.a[kk][i] = *(const half8*)(base + a_row + i * 4096 + co);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) f.b[kk][j] = *(const half8*)(base + b_row + j * 4096 + co);
+            }
+        };
+        auto mfma_frags = [&](const Frag& f) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[kk][i], f.b[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        const int nk = p.ksteps;
+        load_tile(0);
+        if (nk > 1) load_tile(1);
+        if (nk > 2) load_tile(2);
+        // tile 0 landed: at most min(nk-1, 2) younger tiles may stay in flight
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        Frag f0, f1;
+        read_frags(0, f0);
+        int st1 = 1, st0 = 0;  // stage of tile kt+1, stage of tile kt (refilled with tile kt+3)
+        auto step = [&](int kt, Frag& cur, Frag& nxt) {
+            if (kt + 1 < nk) {  // tile kt+1 landed; only tile kt+2 may still be in flight
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of tile kt are in registers
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) load_tile(st0);
+            if (kt + 1 < nk) read_frags(st1, nxt);
+            mfma_frags(cur);
+            st0 = st0 == 2 ? 0 : st0 + 1;
+            st1 = st1 == 2 ? 0 : st1 + 1;
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            step(kt, f0, f1);
+            step(kt + 1, f1, f0);
+        }
+        if (kt < nk) step(kt, f0, f1);
+        __syncthreads();  // LDS is reused by the epilogue
     }
 
-    // ---- epilogue: accumulators -> LDS f32 [m][ch]
+    // ---- epilogue: accumulators -> LDS f32 [m][ch] (TM / EPI rows per round), then coalesced rows
     float* E = (float*)lds;
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-#pragma unroll
-        for (int j = 0; j < TMT; ++j) {
-            const int m_l = wm * WTM + j * 32 + l31;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch_l = wc * WTC + i * 32 + 8 * g + 4 * lh;
-                f32x4 v = { acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3] };
-                *(f32x4*)(E + m_l * ES + ch_l) = v;
-            }
-        }
-    __syncthreads();
-
-    constexpr int TPR = TCH / 8, RPP = 256 / TPR, NPASS = TM / RPP;
+    constexpr int TPR = TCH / 8, RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
     const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
     const int ch = ch_tile * TCH + ch_l;
-    if (ch >= p.cout8) return;
+    const bool ch_ok = ch < p.cout8;
     float bias8[8];
     {
-        const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);
+        const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);  // bias is padded to coutPad
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
@@ -189,51 +255,72 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParams p) {
             ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
         }
     };
-    // all residual rows of this thread are requested up front (one latency, not NPASS of them)
-    half8 rv[NPASS];
-    if (p.res) {
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int m = m_tile * TM + pass * RPP + rr;
-            long long yo, ro;
-            offsets(m < p.M ? m : 0, yo, ro);
-            rv[pass] = *(const half8*)(p.res + ro);
+    for (int h = 0; h < EPI; ++h) {
+        // all residual rows of this thread for this round are requested up front (one latency)
+        half8 rv[NPASS];
+        if (p.res && ch_ok) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m_tile * TM + h * EROWS + pass * RPP + rr;
+                long long yo, ro;
+                offsets(m < p.M ? m : 0, yo, ro);
+                rv[pass] = *(const half8*)(p.res + ro);
+            }
         }
-    }
+        if (EPI == 1 || wm / WMG == h) {
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int m_l = pass * RPP + rr, m = m_tile * TM + m_l;
-        if (m < p.M) {
-            const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
-            float v[8];
+            for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-            long long yo, ro;
-            offsets(m, yo, ro);
-            if (p.res) {
+                for (int j = 0; j < TMT; ++j) {
+                    const int m_l = (wm % WMG) * WTM + j * 32 + l31;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-            }
-            if (ch + 8 > p.tanh_from) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
-            }
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-            *(half8*)(p.y + yo) = o;
+                    for (int g = 0; g < 4; ++g) {
+                        const int c_l = wc * WTC + i * 32 + 8 * g + 4 * lh;
+                        f32x4 v = { acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3] };
+                        *(f32x4*)(E + m_l * ES + c_l) = v;
+                    }
+                }
         }
+        __syncthreads();
+        if (ch_ok) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
+                if (m < p.M) {
+                    const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+                    long long yo, ro;
+                    offsets(m, yo, ro);
+                    if (p.res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                    if (ch + 8 > p.tanh_from) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                    *(half8*)(p.y + yo) = o;
+                }
+            }
+        }
+        if (h + 1 < EPI) __syncthreads();
     }
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
-                 case TILE_32x256: return 32; case TILE_256x128: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x256: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+                 case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
@@ -241,11 +328,13 @@ int conv_tile_m(ConvTile t) {
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
-        case TILE_128x128: return "conv_igemm_f16<128,128,2,2,0>";
-        case TILE_64x256: return "conv_igemm_f16<64,256,1,4,0>";
-        case TILE_32x256: return "conv_igemm_f16<32,256,1,4,0>";
-        case TILE_64x256_SMALLC: return "conv_igemm_f16<64,256,1,4,1>";
-        case TILE_256x128: return "conv_igemm_f16<256,128,4,1,0>";
+        case TILE_128x128: return "conv_igemm_f16<128,128,2,2,0,2>";
+        case TILE_64x256: return "conv_igemm_f16<64,256,1,4,0,2>";
+        case TILE_32x256: return "conv_igemm_f16<32,256,1,4,0,2>";
+        case TILE_64x256_SMALLC: return "conv_igemm_f16<64,256,1,4,1,2>";
+        case TILE_256x128: return "conv_igemm_f16<256,128,4,2,0,3>";
+        case TILE_128x256: return "conv_igemm_f16<128,256,2,4,0,3>";
+        case TILE_256x256: return "conv_igemm_f16<256,256,2,4,0,2>";
     }
     return "?";
 }
@@ -253,12 +342,15 @@ const char* conv_tile_symbol(ConvTile t) {
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm;
-    const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles)), block(256);
+    const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
     switch (tile) {
-        case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false>), grid, block, 0, stream, p); break;
-        case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false>), grid, block, 0, stream, p); break;
-        case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false>), grid, block, 0, stream, p); break;
-        case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true>), grid, block, 0, stream, p); break;
+        case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true, 2, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
+        case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
+        case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -31,14 +31,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define YH_K1_ROWS 64
 __global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
     extern __shared__ __attribute__((aligned(16))) float zs[];  // [192][C]
-    const int C = p.C, tid = threadIdx.x;
-    const long long rows = (long long)p.n * p.cells;
-    const long long r0 = (long long)blockIdx.x * YH_K1_ROWS;
+    const int C = p.C, tid = threadIdx.x, b = blockIdx.y;
+    const int c0 = blockIdx.x * YH_K1_ROWS;       // first cell of this workgroup, within frame b
+    const half_t* rows = p.heads + ((long long)b * p.cells + c0) * p.ldh;
+    const int nrows = p.cells - c0 < YH_K1_ROWS ? p.cells - c0 : YH_K1_ROWS;
     const int chunks = p.ldh / 8;  // 16-byte chunks per row
-    for (int i = tid; i < YH_K1_ROWS * chunks; i += 192) {
+    for (int i = tid; i < nrows * chunks; i += 192) {
         const int rl = i / chunks, j = i - rl * chunks;
-        if (r0 + rl >= rows) continue;
-        const half8 v = *(const half8*)(p.heads + (r0 + rl) * p.ldh + j * 8);
+        const half8 v = *(const half8*)(rows + (long long)rl * p.ldh + j * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int q = j * 8 + e - 12;
@@ -46,22 +46,29 @@ __global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
         }
     }
     __syncthreads();
-    const long long row = r0 + tid / 3;
-    if (row >= rows) return;
-    const int b = (int)(row / p.cells), cell = (int)(row - (long long)b * p.cells);
-    const int pr = cell * 3 + tid % 3;
+    const bool valid = tid / 3 < nrows;
+    const int pr = (c0 + tid / 3) * 3 + tid % 3;
     float* z = zs + tid * C;
-    float m = z[0];
-    for (int c = 1; c < C; ++c) { const float v = z[c]; m = v > m ? v : m; }
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) { const float e = spec_expf(__fsub_rn(z[c], m)); z[c] = e; s = __fadd_rn(s, e); }
+    float s = 1.0f;
+    if (valid) {
+        float m = z[0];
+        for (int c = 1; c < C; ++c) { const float v = z[c]; m = v > m ? v : m; }
+        s = 0.0f;
+        for (int c = 0; c < C; ++c) { const float e = spec_expf(__fsub_rn(z[c], m)); z[c] = e; s = __fadd_rn(s, e); }
+    }
+    // wave-aggregated append: one atomic per (wave, class) that has any candidate
+    const int lane = tid & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int c = 1; c < C; ++c) {
-        const float pc = __fdiv_rn(z[c], s);
-        if (pc > p.conf_thresh) {
-            const int list = b * (C - 1) + (c - 1);
-            const int slot = atomicAdd(&p.cls_count[list], 1);
-            p.cand[(long long)list * p.P + slot] = make_uint2(__float_as_uint(pc), (unsigned)pr);
-        }
+        const float pc = valid ? __fdiv_rn(z[c], s) : 0.0f;
+        const bool hit = pc > p.conf_thresh;
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;  // wave-uniform
+        const int list = b * (C - 1) + (c - 1);
+        int base = 0;
+        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&p.cls_count[list], __popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1);
+        if (hit) p.cand[(long long)list * p.P + base + __popcll(mask & lt)] = make_uint2(__float_as_uint(pc), (unsigned)pr);
     }
 }
 
@@ -305,8 +312,7 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
     switch (stage) {
         case 0: return hipMemsetAsync(p.cls_count, 0, sizeof(int) * (size_t)p.n * (p.C - 1), s);
         case 1: {
-            const long long rows = (long long)p.n * p.cells;
-            hipLaunchKernelGGL(det_softmax_cand, dim3((unsigned)((rows + YH_K1_ROWS - 1) / YH_K1_ROWS)), dim3(192),
+            hipLaunchKernelGGL(det_softmax_cand, dim3((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n), dim3(192),
                                (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }

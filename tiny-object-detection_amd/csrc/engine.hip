@@ -124,6 +124,7 @@ struct yh_engine {
     bool weights_loaded = false;
     int cur_n = 0;
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
+    std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -217,8 +218,10 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     else if (cout <= 32) p.tile = TILE_32x256;
     else if (cout <= 64) p.tile = TILE_64x256;
     else p.tile = TILE_128x128;
-    p.coutPad = round_up(cout, conv_tile_ch(p.tile));
     p.Kpad = d0.cin == 3 ? round_up(d0.k * d0.k, 8) * 8 : d0.k * d0.k * d0.cin;
+    // K-heavy layers (>= 8 steps of 64): 8-wave tiles on the 3-stage LDS-DMA ring
+    if (p.tile == TILE_128x128 && p.Kpad >= 512) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    p.coutPad = round_up(cout, conv_tile_ch(p.tile));
     h->panels.push_back(p);
     return (int)h->panels.size() - 1;
 }
@@ -426,6 +429,17 @@ int alloc_tail(yh_engine* h) {
 // ------------------------------------------------------------------------------------------------
 // launching
 // ------------------------------------------------------------------------------------------------
+// The panel fixes the widest channel tile (coutPad); per launch, fall back to the 4-wave
+// 128 x 128 tile (2 workgroups per CU) when the big tile would leave most of the 256 CUs idle.
+ConvTile pick_tile(const Panel& pn, int M) {
+    if (pn.tile == TILE_256x256 || pn.tile == TILE_128x256) {
+        const int tm = conv_tile_m(pn.tile), tch = conv_tile_ch(pn.tile);
+        const long long blocks = (long long)((M + tm - 1) / tm) * (pn.coutPad / tch);
+        if (blocks < 192) return TILE_128x128;
+    }
+    return pn.tile;
+}
+
 int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const Panel& pn = h->panels[o.panel];
     ConvParams p;
@@ -448,7 +462,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const long long pq = (long long)o.P * o.Q;
     p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
     p.act = o.act; p.tanh_from = o.tanh_from;
-    p.n_ch_tiles = pn.coutPad / conv_tile_ch(pn.tile);
+    p.n_ch_tiles = pn.coutPad / conv_tile_ch(pick_tile(pn, p.M));
     if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
     *out = p;
     return YH_OK;
@@ -464,7 +478,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             ConvParams p;
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
-            e = launch_conv(p, h->panels[o.panel].tile, h->stream);
+            e = launch_conv(p, pick_tile(h->panels[o.panel], p.M), h->stream);
             break;
         }
         case OP_POOL:
@@ -985,12 +999,16 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
     }
     for (auto& e : ev) hipEventDestroy(e);
     if (rc) return rc;
+    h->prof_labels.assign(nl, std::string());
     for (int i = 0; i < nl; ++i) {
         ms[i] = (float)(acc[i] / reps);
         const bool isop = i < nops;
+        if (isop && h->ops[i].kind == OP_CONV)  // the tile (hence the kernel symbol) is chosen per launch
+            h->prof_labels[i] = std::string(conv_tile_symbol(pick_tile(h->panels[h->ops[i].panel], n * h->ops[i].P * h->ops[i].Q))) + ":" + h->ops[i].name;
+        else h->prof_labels[i] = isop ? h->ops[i].label : detect_stage_name(i - nops);
         if (flops) flops[i] = isop ? h->ops[i].flops_per_img * n : 0.0;
         if (bytes) bytes[i] = isop ? h->ops[i].bytes_per_img * n + h->ops[i].bytes_fixed : 0.0;
-        if (names) names[i] = isop ? h->ops[i].label.c_str() : detect_stage_name(i - nops);
+        if (names) names[i] = h->prof_labels[i].c_str();
     }
     return YH_OK;
 }
@@ -1018,8 +1036,9 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     const int P = out_dim(hh, k, stride, pad), Q = out_dim(ww, k, stride, pad);
     if (P < 1 || Q < 1) return h->fail(YH_EINVAL, "conv op: empty output");
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
-    const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
+    if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8
     std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
     for (size_t i = 0; i < (size_t)n * hh * ww; ++i) memcpy(&xs[i * cs], &x[i * cin], (size_t)cin * 2);
