@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: world_size 2 over gloo (127.0.0.1). Frames shard with no data-path
+collective; the one collective is the weight-blob broadcast from rank 0; step time is the MAX
+over ranks. Uses the same helpers bench.py runs on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, nbytes, out_dir):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blob = torch.zeros(nbytes, dtype=torch.uint8)
+        if rank == 0:
+            rng = np.random.default_rng(7)
+            blob.copy_(torch.from_numpy(rng.integers(0, 256, nbytes, dtype=np.uint8)))
+        bench.broadcast_weights(dist, blob)
+        start, count = bench.shard_frames(129, world, rank)
+        t = bench.max_over_ranks(dist, 1.0 + rank, "cpu")
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([int(blob.sum()), start, count, t], np.float64))
+        np.save(os.path.join(out_dir, f"b{rank}.npy"), blob.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_shard_and_timing(tmp_path):
+    world, nbytes = 2, 1 << 16
+    mp.spawn(_worker, args=(world, _free_port(), nbytes, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"r{k}.npy") for k in range(world)]
+    b = [np.load(tmp_path / f"b{k}.npy") for k in range(world)]
+    assert np.array_equal(b[0], b[1]) and b[0].any()            # rank 1 received rank 0's blob
+    assert (r[0][1], r[0][2]) == (0, 65) and (r[1][1], r[1][2]) == (65, 64)   # contiguous blocks of 129 frames
+    assert r[0][3] == r[1][3] == 2.0                            # MAX over ranks
+
+
+def test_shard_frames_partitions_exactly():
+    import bench
+    for total in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 4, 8):
+            spans = [bench.shard_frames(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_roofline_helper_picks_dominant_kernel():
+    import bench
+    prof = [dict(name="conv_a:l1", ms=2.0, flops=4e12, bytes=1e9), dict(name="conv_a:l2", ms=1.0, flops=2e12, bytes=1e9),
+            dict(name="pool:p", ms=0.5, flops=0.0, bytes=2e9)]
+    r = bench.roofline_of(prof)
+    assert r["kernel"] == "conv_a" and r["bound"] == "mfma" and r["launches"] == 2
+    assert abs(r["achieved"] - 2000.0) < 1e-6 and abs(r["frac"] - 0.8) < 1e-9

@@ -95,34 +95,45 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // position of the NEXT tile to load along K
     int kr = 0, ks = 0, kc = 0, kt_load = 0;
 
-    auto load_tile = [&](int buf) {
-        int r, s, rs_off;
+    // One tile's DMA is NDMA instructions per thread (WL weight pieces, then XL activation pieces).
+    // tile_begin fixes the tile's K position, tile_part issues piece d, tile_end advances K.
+    constexpr int NDMA = XL + WL;
+    int t_r = 0, t_s = 0, t_off = 0;
+    auto tile_begin = [&]() {
         if (SMALLC) {
             const int2 tap = p.rs_table[kt_load * 8 + lc];
-            r = tap.x; s = tap.y;
-            rs_off = (r * p.W + s) * 8;
+            t_r = tap.x; t_s = tap.y;
+            t_off = (t_r * p.W + t_s) * 8;
         } else {
-            r = kr; s = ks;
-            rs_off = (kr * p.W + ks) * p.C + kc;
+            t_r = kr; t_s = ks;
+            t_off = (kr * p.W + ks) * p.C + kc;
         }
+    };
+    auto tile_part = [&](int buf, int d) {
         lds_char* const dstw = lds3 + buf * AB_BYTES + wave * 1024;
-        lds_char* const dstx = dstw + TCH * 128;
-#pragma unroll
-        for (int i = 0; i < WL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + i * (RSTEP * 128), 16,
-                                                     (int)(wbase + (unsigned)((RSTEP * i) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const bool ok = (unsigned)(xih[i] + r) < (unsigned)p.H && (unsigned)(xiw[i] + s) < (unsigned)p.W;
+        if (d < WL) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + d * (RSTEP * 128), 16,
+                                                     (int)(wbase + (unsigned)((RSTEP * d) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
+        } else {
+            const int i = d - WL;
+            const bool ok = (unsigned)(xih[i] + t_r) < (unsigned)p.H && (unsigned)(xiw[i] + t_s) < (unsigned)p.W;
             // padded taps read the 16-byte zero block that ends every activation allocation
-            const unsigned voff = ok ? (unsigned)(xbase[i] + rs_off) * 2u : p.x_zero_off;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstx + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
+            const unsigned voff = ok ? (unsigned)(xbase[i] + t_off) * 2u : p.x_zero_off;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstw + TCH * 128 + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
         }
+    };
+    auto tile_end = [&]() {
         ++kt_load;
         if (!SMALLC) {
             kc += 64;
             if (kc >= p.C) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
         }
+    };
+    auto load_tile = [&](int buf) {
+        tile_begin();
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) tile_part(buf, d);
+        tile_end();
     };
 
     const int lane = tid & 63, wid = tid >> 6;
@@ -157,12 +168,35 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     };
 
     if (STAGES == 2) {
+        // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
+        // step k, between that slice's fragment reads and its MFMAs: DMA issue (the expensive
+        // part of LDS-DMA for the issuing wave) overlaps MFMA execution instead of preceding it.
         load_tile(0);
         __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
         int cur = 0;
         for (int kt = 0; kt < p.ksteps; ++kt) {
-            if (kt + 1 < p.ksteps) load_tile(cur ^ 1);  // DMA of step k+1 flies under the MFMAs of step k
-            compute(cur);
+            const bool more = kt + 1 < p.ksteps;
+            const char* base = lds + cur * AB_BYTES;
+            if (more) tile_begin();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((2 * kk + lh) ^ swz) << 4;
+                half8 a[TC], b[TMT];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base + a_row + i * 4096 + co);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base + b_row + j * 4096 + co);
+                if (more) {
+#pragma unroll
+                    for (int d = (kk * NDMA) / 4; d < ((kk + 1) * NDMA) / 4; ++d) tile_part(cur ^ 1, d);
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) tile_end();
             __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
             cur ^= 1;
         }
@@ -173,7 +207,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         // so the MFMAs of a step never wait on LDS latency (their operands were read one step
         // earlier) and every DMA has two steps to land. Stage k is free for refill after the
         // barrier because every wave drained its reads of tile k (lgkmcnt(0)) before arriving.
-        constexpr int NDMA = XL + WL;  // this wave's DMA instructions per tile
         struct Frag { half8 a[4][TC], b[4][TMT]; };
         auto read_frags = [&](int buf, Frag& f) {
             const char* base = lds + buf * AB_BYTES;
