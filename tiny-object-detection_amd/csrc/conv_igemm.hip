@@ -352,12 +352,12 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x256: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x256: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
                  case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_256x128: return 128; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_256x128: return 128; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -368,6 +368,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_256x128: return "conv_igemm_f16<256,128,4,2,0,3>";
         case TILE_128x256: return "conv_igemm_f16<128,256,2,4,0,3>";
         case TILE_256x256: return "conv_igemm_f16<256,256,2,4,0,2>";
+        case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
     }
     return "?";
 }
@@ -383,6 +384,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
+        case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }

@@ -58,6 +58,9 @@ struct Op {
     int stride = 1, pad = 0, act = 0, tanh_from = INT_MAX;
     int P = 0, Q = 0;      // output spatial
     double flops_per_img = 0, bytes_per_img = 0, bytes_fixed = 0;
+    int lane = 0;              // stream the op runs on when branch concurrency is on
+    std::vector<int> deps;     // producer ops on OTHER lanes (RAW through in / res)
+    bool signal = false;       // some op on another lane consumes this op's output
 };
 
 size_t pad16(size_t v) { return (v + 15u) & ~(size_t)15u; }
@@ -87,7 +90,10 @@ struct yh_engine {
     yh_config cfg;
     int dev = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static const int kLanes = 4;
+    hipStream_t lanes[kLanes] = { nullptr, nullptr, nullptr, nullptr };  // lanes[0] == stream
+    std::vector<hipEvent_t> op_done;   // one per op that signals another lane
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
     std::string err;
 
     int S = 0, C = 0, ldh = 0;
@@ -374,6 +380,27 @@ int build_graph_spec(yh_engine* h) {
         h->ops.push_back(o);
     }
     if (ci != (int)h->convs.size()) return h->fail(YH_EINVAL, "conv table / graph mismatch");
+    // ---- branch concurrency: lanes by role, cross-lane RAW dependencies found by buffer pointer
+    // (every tensor is written exactly once per step and never aliased, so RAW is the only hazard)
+    for (Op& o : h->ops) {
+        const std::string& n = o.name;
+        auto ends = [&](const char* suf) { const size_t l = strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
+        if (ends("_d") || n == "p5" || n == "p6" || n == "p7" || n == "head_t2" || n == "head_out2" || n == "head_t3" ||
+            n == "head_out3" || n == "head_t4" || n == "head_out4") o.lane = 1;
+        else if (n == "p4" || n == "head_t1" || n == "head_out1") o.lane = 2;
+        else if (n == "head_t0" || n == "head_out0") o.lane = 3;
+        else o.lane = 0;
+    }
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        Op& o = h->ops[i];
+        const half_t* srcs[2] = { o.kind == OP_PRE ? nullptr : o.in.d, o.has_res ? o.res.d : nullptr };
+        for (const half_t* sp : srcs) {
+            if (!sp) continue;
+            for (size_t j = 0; j < i; ++j)
+                if (h->ops[j].kind != OP_PRE ? h->ops[j].out.d == sp : h->in_f16.d == sp)
+                    if (h->ops[j].lane != o.lane) { o.deps.push_back((int)j); h->ops[j].signal = true; }
+        }
+    }
     h->flops_per_frame = 0;
     for (const Op& o : h->ops) h->flops_per_frame += o.flops_per_img;
     return YH_OK;
@@ -435,7 +462,16 @@ ConvTile pick_tile(const Panel& pn, int M) {
     if (pn.tile == TILE_256x256 || pn.tile == TILE_128x256) {
         const int tm = conv_tile_m(pn.tile), tch = conv_tile_ch(pn.tile);
         const long long blocks = (long long)((M + tm - 1) / tm) * (pn.coutPad / tch);
-        if (blocks < 192) return TILE_128x128;
+        if (blocks < 192) {
+            // latency-bound launches (at most one workgroup per CU): the 3-stage ring hides the
+            // L2 round trip of every 64-deep K step
+            const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
+            return b128 <= 256 ? TILE_128x128_S3 : TILE_128x128;
+        }
+    }
+    if (pn.tile == TILE_128x128 && pn.Kpad >= 256) {
+        const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
+        if (b128 <= 256) return TILE_128x128_S3;
     }
     return pn.tile;
 }
@@ -492,8 +528,39 @@ int launch_op(yh_engine* h, const Op& o, int n) {
     return YH_OK;
 }
 
+int launch_op_on(yh_engine* h, const Op& o, int n, hipStream_t st) {
+    hipStream_t keep = h->stream;
+    h->stream = st;
+    const int rc = launch_op(h, o, n);
+    h->stream = keep;
+    return rc;
+}
+
 int enqueue_all(yh_engine* h, int n, int with_tail) {
-    for (const Op& o : h->ops) { int rc = launch_op(h, o, n); if (rc) return rc; }
+    // Small batches leave most CUs idle inside each launch: independent branches (projection
+    // convs, FPN levels, the shared head per level, the protonet) then run on their own streams,
+    // joined by events (also valid under stream capture: the lanes fork from and join the origin).
+    const bool multi = n <= 8;
+    if (!multi) {
+        for (const Op& o : h->ops) { int rc = launch_op(h, o, n); if (rc) return rc; }
+    } else {
+        bool used[yh_engine::kLanes] = { true, false, false, false };
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // fork point
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const Op& o = h->ops[i];
+            hipStream_t st = h->lanes[o.lane];
+            if (!used[o.lane]) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_fork, 0)); used[o.lane] = true; }
+            for (int j : o.deps) HIPCHK(h, hipStreamWaitEvent(st, h->op_done[j], 0));
+            int rc = launch_op_on(h, o, n, st);
+            if (rc) return rc;
+            if (o.signal) HIPCHK(h, hipEventRecord(h->op_done[i], st));
+        }
+        for (int l = 1; l < yh_engine::kLanes; ++l)
+            if (used[l]) {  // join
+                HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + l], h->lanes[l]));
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + l], 0));
+            }
+    }
     if (with_tail) {
         h->det.n = n;
         hipError_t e = launch_detect(h->det, h->stream);
@@ -657,12 +724,18 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     };
     hipError_t e = hipSetDevice(h->dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    h->lanes[0] = h->stream;
+    for (int l = 1; l < yh_engine::kLanes && e == hipSuccess; ++l) e = hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev0, hipEventDefault);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("device setup: ") + hipGetErrorString(e); return bail(YH_EHIP); }
     build_conv_table(h);
     int rc = build_graph_spec(h);
     if (rc) return bail(rc);
+    h->op_done.assign(h->ops.size() + yh_engine::kLanes, nullptr);
+    for (auto& ev : h->op_done)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { h->err = "hipEventCreate"; return bail(YH_EHIP); }
     build_priors(h);
     if ((rc = alloc_tail(h))) return bail(rc);
     if ((rc = alloc_panels(h))) return bail(rc);
@@ -685,7 +758,10 @@ void yh_destroy(yh_engine* h) {
     if (h->codes_dev) hipFree(h->codes_dev);
     if (h->stitch_dev) hipFree(h->stitch_dev);
     if (h->diverged_dev) hipFree(h->diverged_dev);
+    for (hipEvent_t ev : h->op_done) if (ev) hipEventDestroy(ev);
+    for (int l = 1; l < yh_engine::kLanes; ++l) if (h->lanes[l]) { hipStreamSynchronize(h->lanes[l]); hipStreamDestroy(h->lanes[l]); }
     if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
