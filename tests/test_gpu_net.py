@@ -140,11 +140,17 @@ def test_batch_of_two_equals_two_singles(setup, golden_dir):
     eng.set_input(img)
     eng.invoke()
     both = [eng.output(i) for i in range(4)]
+    # The tile shape (and, for launches with only a few tiles, a split-K with slab reduction) is
+    # chosen from M = n*P*Q, so the f32 summation order may differ between batch sizes: results
+    # agree to f16 rounding of that reordering, and are bitwise reproducible for a given n.
     for f in range(2):
         eng.set_input(img[f:f + 1])
         eng.invoke()
+        first = [eng.output(i)[0] for i in range(4)]
+        eng.invoke()
         for i in range(4):
-            assert np.array_equal(eng.output(i)[0], both[i][f])
+            assert np.array_equal(eng.output(i)[0], first[i])                    # reproducible
+            assert np.abs(first[i] - both[i][f]).max() <= 0.02 * max(1.0, np.abs(both[i][f]).max())
 
 
 def test_graph_replay_equals_eager(built, golden_dir):

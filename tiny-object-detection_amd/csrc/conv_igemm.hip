@@ -37,7 +37,11 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 //              per tile) and a raw s_barrier, so one tile stays in flight across every barrier.
 // EPI: the epilogue's f32 staging image covers TM / EPI rows at a time (a 256 x 256 tile's does not
 //      fit in LDS at once).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI>
+// SPLITK: the grid also splits K into p.k_slices ranges; each workgroup writes its raw f32 partial
+//      tile to p.partial[slice][m][ch] and splitk_reduce_f16 sums the slices in order (fixed order:
+//      bitwise reproducible), adds bias/residual, activates and rounds. For launches whose M gives
+//      only a handful of tiles (batch 1, deep layers: 12 workgroups streaming 4.7 MB of weights).
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
@@ -57,7 +61,15 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ch_tile = wg % p.n_ch_tiles, m_tile = wg / p.n_ch_tiles;
+    int tile_id = wg, kslice = 0, kt0 = 0, nk_total = p.ksteps;
+    if (SPLITK) {  // slice is the slow index: neighbours share the K range (weights / activations in L2)
+        const int ntiles = nwg / p.k_slices;
+        kslice = wg / ntiles;
+        tile_id = wg - kslice * ntiles;
+        kt0 = kslice * p.ksteps_per_slice;
+        nk_total = p.ksteps - kt0 < p.ksteps_per_slice ? p.ksteps - kt0 : p.ksteps_per_slice;
+    }
+    const int ch_tile = tile_id % p.n_ch_tiles, m_tile = tile_id / p.n_ch_tiles;
 
     const int tid = threadIdx.x, chunk = tid & 7, rb = tid >> 3;
     const int PQ = p.P * p.Q;
@@ -93,7 +105,13 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     lds_char* const lds3 = (lds_char*)lds;
 
     // position of the NEXT tile to load along K
-    int kr = 0, ks = 0, kc = 0, kt_load = 0;
+    int kr = 0, ks = 0, kc = 0, kt_load = kt0;
+    if (SPLITK && !SMALLC) {
+        const int cpb = p.C >> 6, rs = kt0 / cpb;
+        kc = (kt0 - rs * cpb) << 6;
+        kr = rs / p.S;
+        ks = rs - kr * p.S;
+    }
 
     // One tile's DMA is NDMA instructions per thread (WL weight pieces, then XL activation pieces).
     // tile_begin fixes the tile's K position, tile_part issues piece d, tile_end advances K.
@@ -149,24 +167,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    auto compute = [&](int buf) {
-        const char* base = lds + buf * AB_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int co = ((2 * kk + lh) ^ swz) << 4;
-            half8 a[TC], b[TMT];
-#pragma unroll
-            for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base + a_row + i * 4096 + co);
-#pragma unroll
-            for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base + b_row + j * 4096 + co);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TMT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
     if (STAGES == 2) {
         // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
         // step k, between that slice's fragment reads and its MFMAs: DMA issue (the expensive
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         load_tile(0);
         __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
         int cur = 0;
-        for (int kt = 0; kt < p.ksteps; ++kt) {
-            const bool more = kt + 1 < p.ksteps;
+        for (int kt = 0; kt < nk_total; ++kt) {
+            const bool more = kt + 1 < nk_total;
             const char* base = lds + cur * AB_BYTES;
             if (more) tile_begin();
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[kk][i], f.b[kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        const int nk = p.ksteps;
+        const int nk = nk_total;
         load_tile(0);
         if (nk > 1) load_tile(1);
         if (nk > 2) load_tile(2);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     for (int h = 0; h < EPI; ++h) {
         // all residual rows of this thread for this round are requested up front (one latency)
         half8 rv[NPASS];
-        if (p.res && ch_ok) {
+        if (!SPLITK && p.res && ch_ok) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m = m_tile * TM + h * EROWS + pass * RPP + rr;
@@ -316,7 +316,17 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                 }
         }
         __syncthreads();
-        if (ch_ok) {
+        if (SPLITK) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
+                if (m < p.M) {
+                    float* dst = p.partial + ((long long)kslice * p.M + m) * p.partial_ld + ch;
+                    *(f32x4*)dst = *(const f32x4*)(E + m_l * ES + ch_l);
+                    *(f32x4*)(dst + 4) = *(const f32x4*)(E + m_l * ES + ch_l + 4);
+                }
+            }
+        } else if (ch_ok) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
@@ -351,6 +361,51 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     }
 }
 
+// Sums the split-K partial slabs in slice order, then the usual epilogue. One lane = 8 channels of
+// one output row: 32-byte f32 reads per slice, one 16-byte f16 store.
+__global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
+    const int groups = p.cout8 >> 3;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)p.M * groups) return;
+    const int m = (int)(t / groups), ch = (int)(t - (long long)m * groups) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    for (int sl = 0; sl < p.k_slices; ++sl) {
+        const float* src = p.partial + ((long long)sl * p.M + m) * p.partial_ld + ch;
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] + p.bias[ch + e];
+    long long yo, ro;
+    if (p.y_dense) { yo = (long long)m * p.ldy + ch; ro = (long long)m * p.ldres + ch; }
+    else {
+        const int PQ = p.P * p.Q, n = m / PQ, rem = m - n * PQ;
+        yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
+        ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
+    }
+    if (p.res) {
+        const half8 rv = *(const half8*)(p.res + ro);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if (ch + 8 > p.tanh_from) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    *(half8*)(p.y + yo) = o;
+}
+
 int conv_tile_ch(ConvTile t) {
     switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x256: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
                  case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: return 256; }
@@ -376,6 +431,14 @@ const char* conv_tile_symbol(ConvTile t) {
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm;
+    if (p.k_slices > 1) {
+        if (tile != TILE_128x128_S3) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), dim3((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices)),
+                           dim3(256), 0, stream, p);
+        const long long work = (long long)p.M * (p.cout8 >> 3);
+        hipLaunchKernelGGL(splitk_reduce_f16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
     switch (tile) {
         case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1>), grid, dim3(256), 0, stream, p); break;

@@ -86,6 +86,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 
 }  // namespace
 
+static const int yh_engine_lanes = 4;
 struct yh_engine {
     yh_config cfg;
     int dev = 0;
@@ -126,6 +127,8 @@ struct yh_engine {
     // output staging
     float* out_f32 = nullptr;
     size_t out_f32_cap = 0;
+    float* splitk_ws[yh_engine_lanes] = { nullptr, nullptr, nullptr, nullptr };  // one per lane (lanes run concurrently)
+    static const size_t kSplitKBytes = (size_t)48 << 20;
 
     bool weights_loaded = false;
     int cur_n = 0;
@@ -498,7 +501,24 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const long long pq = (long long)o.P * o.Q;
     p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
     p.act = o.act; p.tanh_from = o.tanh_from;
-    p.n_ch_tiles = pn.coutPad / conv_tile_ch(pick_tile(pn, p.M));
+    const ConvTile tile = pick_tile(pn, p.M);
+    p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
+    p.k_slices = 1;
+    if (tile == TILE_128x128_S3 && p.ksteps >= 8) {
+        // few tiles, long K: split K so that about one workgroup per CU streams the weights
+        const long long tiles = (long long)((p.M + 127) / 128) * p.n_ch_tiles;
+        int sl = (int)(256 / tiles);
+        if (sl > p.ksteps / 4) sl = p.ksteps / 4;  // at least 4 steps per slice
+        if (sl > 16) sl = 16;
+        const size_t need = (size_t)sl * p.M * pn.coutPad * 4;
+        if (sl >= 2 && need <= yh_engine::kSplitKBytes) {
+            p.k_slices = sl;
+            p.ksteps_per_slice = (p.ksteps + sl - 1) / sl;
+            p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+            p.partial_ld = pn.coutPad;
+            p.partial = h->splitk_ws[o.lane];
+        }
+    }
     if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
     *out = p;
     return YH_OK;
@@ -739,6 +759,11 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     build_priors(h);
     if ((rc = alloc_tail(h))) return bail(rc);
     if ((rc = alloc_panels(h))) return bail(rc);
+    for (int l = 0; l < yh_engine_lanes; ++l) {
+        void* q = nullptr;
+        if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
+        h->splitk_ws[l] = (float*)q;
+    }
     e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
     *out = h;

@@ -41,6 +41,10 @@ struct ConvParams {
     int act;              // 0 none, 1 relu
     int tanh_from;        // channels >= tanh_from get tanh (INT_MAX: none)
     int n_ch_tiles;
+    int k_slices;         // > 1: split-K (partial slabs + splitk_reduce_f16)
+    int ksteps_per_slice;
+    int partial_ld;       // row stride of the partial slabs in floats (coutPad)
+    float* partial;       // [k_slices][M][partial_ld] f32 workspace
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7 };
