@@ -107,8 +107,8 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // position of the NEXT tile to load along K
     int kr = 0, ks = 0, kc = 0, kt_load = kt0;
     if (SPLITK && !SMALLC) {
-        const int cpb = p.C >> 6, rs = kt0 / cpb;
-        kc = (kt0 - rs * cpb) << 6;
+        const int taps = p.R * p.S, cb = kt0 / taps, rs = kt0 - cb * taps;
+        kc = cb << 6;
         kr = rs / p.S;
         ks = rs - kr * p.S;
     }
@@ -116,22 +116,24 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // One tile's DMA is NDMA instructions per thread (WL weight pieces, then XL activation pieces).
     // tile_begin fixes the tile's K position, tile_part issues piece d, tile_end advances K.
     constexpr int NDMA = XL + WL;
-    int t_r = 0, t_s = 0, t_off = 0;
+    int t_r = 0, t_s = 0, t_off = 0, t_wk = 0;
     auto tile_begin = [&]() {
         if (SMALLC) {
             const int2 tap = p.rs_table[kt_load * 8 + lc];
             t_r = tap.x; t_s = tap.y;
             t_off = (t_r * p.W + t_s) * 8;
+            t_wk = kt_load * 64;
         } else {
             t_r = kr; t_s = ks;
             t_off = (kr * p.W + ks) * p.C + kc;
+            t_wk = (kr * p.S + ks) * p.C + kc;   // K index of this step in the [(r,s,c)] weight panel
         }
     };
     auto tile_part = [&](int buf, int d) {
         lds_char* const dstw = lds3 + buf * AB_BYTES + wave * 1024;
         if (d < WL) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + d * (RSTEP * 128), 16,
-                                                     (int)(wbase + (unsigned)((RSTEP * d) * p.ldw + kt_load * 64) * 2u), 0, 0, 0);
+                                                     (int)(wbase + (unsigned)((RSTEP * d) * p.ldw + t_wk) * 2u), 0, 0, 0);
         } else {
             const int i = d - WL;
             const bool ok = (unsigned)(xih[i] + t_r) < (unsigned)p.H && (unsigned)(xiw[i] + t_s) < (unsigned)p.W;
@@ -143,8 +145,11 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     auto tile_end = [&]() {
         ++kt_load;
         if (!SMALLC) {
-            kc += 64;
-            if (kc >= p.C) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+            // K order: 64-channel chunk OUTER, taps INNER. The R*S taps of one chunk read the same
+            // input lines (shifted by one pixel / one row) in consecutive steps, so per XCD the
+            // live set is ~(tile pixels + halo) * 128 B * 32 CUs + the chunk's weights: it fits
+            // the 4 MiB L2, where tap-outer order streamed ~8 MB between two uses of a line.
+            if (++ks == p.S) { ks = 0; if (++kr == p.R) { kr = 0; kc += 64; } }
         }
     };
     auto load_tile = [&](int buf) {

@@ -9,6 +9,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -501,6 +502,10 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const long long pq = (long long)o.P * o.Q;
     p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
     p.act = o.act; p.tanh_from = o.tanh_from;
+    // timing-only ablation (tools/): zero-record descriptors drop every load through them
+    static const int ablate = getenv("YH_ABLATE") ? atoi(getenv("YH_ABLATE")) : 0;
+    if (ablate & 1) { p.x_bytes = 0; }
+    if (ablate & 2) { p.w_bytes = 0; }
     const ConvTile tile = pick_tile(pn, p.M);
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
