@@ -192,6 +192,11 @@ int yh_time_steps(yh_engine* h, int32_t with_tail, int32_t steps, float* ms_tota
 /* Algorithmic conv FLOPs of one frame for this architecture (2 x MAC, convs only). */
 double yh_flops_per_frame(const yh_engine* h);
 
+/* Test hook: copies the named intermediate tensor of the last forward (layer names of DESIGN.md:
+ * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
+ * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. */
+int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst_host, size_t nfloats, int32_t dims[4]);
+
 /* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */
 
 /* One NHWC f16 convolution on the MFMA implicit-GEMM kernel with fused bias (+residual) (+act).

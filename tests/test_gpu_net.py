@@ -62,6 +62,22 @@ def test_head_outputs_vs_oracle(setup, golden_dir):
     assert np.array_equal(cells.reshape(2, g * g, 81), got[1][:, 0:g * g * 3:3, :])
 
 
+def test_intermediate_layers_vs_oracle(setup, golden_dir):
+    """Layer by layer (names shared with the oracle): catches a wrong layer that a later ReLU or
+    the whole-net tolerance could mask. Same tolerance model as the heads, tighter early on."""
+    eng, net, _ = setup
+    img = _frames(golden_dir)
+    eng.set_input(img)
+    eng.invoke()
+    net.forward(img, f16=True)
+    for name, tol in (("stem", 2e-3), ("pool", 2e-3), ("c2", 6e-3), ("c3", 1e-2), ("c4", 1.5e-2), ("c5", 2e-2), ("lat5", 2e-2),
+                      ("up5", 2e-2), ("lat4", 2e-2), ("lat3", 2e-2), ("p3", 2e-2), ("p5", 2e-2), ("p7", 2.5e-2),
+                      ("proto2", 2.5e-2), ("proto_up", 2.5e-2), ("proto3", 3e-2), ("head_t0", 3e-2), ("head_t4", 3e-2)):
+        a, b = eng.tensor(name), net.get(name)
+        assert a.shape == b.shape, name
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()))
+
+
 def test_detection_tail_bit_exact_on_equal_inputs(setup, oracle, golden_dir):
     """The tail is specified op for op: on the engine's own head outputs the
     oracle must reproduce class ids, priors, scores, boxes and every mask pixel exactly."""

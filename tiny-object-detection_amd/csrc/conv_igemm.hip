@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         if (SMALLC) {
             const int2 tap = p.rs_table[kt_load * 8 + lc];
             t_r = tap.x; t_s = tap.y;
-            t_off = (t_r * p.W + t_s) * 8;
+            t_off = (t_r * p.W + t_s) * p.C;   // chunk = 16 bytes starting at tap (r,s): 8/C pixels
             t_wk = kt_load * 64;
         } else {
             t_r = kr; t_s = ks;

@@ -12,18 +12,24 @@ namespace yh {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-// u8 RGB -> f16 (v - mean)/std, channels padded 3 -> 8 with zeros (stem runs in small-C mode).
-__global__ __launch_bounds__(256) void preprocess_rgb8_f16(const uint8_t* __restrict__ rgb,
-                                                           half_t* __restrict__ out, long long npix) {
+// u8 RGB -> f16 (v - mean)/std into the stem's input image: 4 channels (r,g,b,0 = 8 bytes per
+// pixel) inside a zero border of 3 pixels (left/top) and >= 5 (right/bottom), so the 7x7 stride-2
+// stem needs no padding logic at all and reads 2 pixels per 16-byte chunk.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void preprocess_rgb8_f16(const uint8_t* __restrict__ rgb, half_t* __restrict__ out,
+                                                           int n, int S, int Hp, int Wp) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)n * S * S;
     if (i >= npix) return;
+    const int x = (int)(i % S);
+    const long long r = i / S;
+    const int y = (int)(r % S), b = (int)(r / S);
     const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
-    half8 o;
+    half4v o;
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = (half_t)(((float)rgb[i * 3 + c] - mean[c]) / sd[c]);
-#pragma unroll
-    for (int c = 3; c < 8; ++c) o[c] = (half_t)0.0f;
-    *(half8*)(out + i * 8) = o;
+    o[3] = (half_t)0.0f;
+    *(half4v*)(out + (((long long)b * Hp + y + 3) * Wp + x + 3) * 4) = o;
 }
 
 __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(256) void cells_f32(const half_t* __restrict__ head
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
-hipError_t launch_preprocess(const uint8_t* rgb, half_t* out8, long long npix, hipStream_t s) {
-    hipLaunchKernelGGL(preprocess_rgb8_f16, dim3(nblk(npix)), dim3(256), 0, s, rgb, out8, npix);
+hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int Hp, int Wp, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_rgb8_f16, dim3(nblk((long long)n * S * S)), dim3(256), 0, s, rgb, out4, n, S, Hp, Wp);
     return hipGetLastError();
 }
 hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s) {

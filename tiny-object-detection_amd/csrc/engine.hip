@@ -111,6 +111,7 @@ struct yh_engine {
     std::map<std::string, Buf> named;
 
     uint8_t* in_u8 = nullptr;
+    int in_hp = 0;
     Buf in_f16, pyr, pyr_t, heads, proto;
     float* priors_dev = nullptr;
     std::vector<float> priors_host;
@@ -220,7 +221,7 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     p.src = src;
     const ConvDesc& d0 = h->convs[src[0]];
     p.k = d0.k;
-    p.cin_store = d0.cin == 3 ? 8 : d0.cin;
+    p.cin_store = d0.cin == 3 ? 4 : d0.cin;   // stem: (r,g,b,0) pixels, two per 16-byte chunk
     int cout = 0;
     for (int s : src) cout += h->convs[s].cout;
     p.cout = cout;
@@ -228,7 +229,7 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     else if (cout <= 32) p.tile = TILE_32x256;
     else if (cout <= 64) p.tile = TILE_64x256;
     else p.tile = TILE_128x128;
-    p.Kpad = d0.cin == 3 ? round_up(d0.k * d0.k, 8) * 8 : d0.k * d0.k * d0.cin;
+    p.Kpad = d0.cin == 3 ? round_up(d0.k * ((d0.k + 1) / 2), 8) * 8 : d0.k * d0.k * d0.cin;  // stem: k rows x ceil(k/2) chunks
     // K-heavy layers (>= 8 steps of 64): 8-wave tiles on the 3-stage LDS-DMA ring
     if (p.tile == TILE_128x128 && p.Kpad >= 512) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
     p.coutPad = round_up(cout, conv_tile_ch(p.tile));
@@ -264,19 +265,27 @@ int build_graph_spec(yh_engine* h) {
     void* p = nullptr;
     if ((rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * S * S * 3))) return rc;
     h->in_u8 = (uint8_t*)p;
-    if ((rc = new_buf(h, "input", S, S, 8, &h->in_f16))) return rc;
+    h->in_hp = S + 8;  // 3-pixel zero border + slack for the stem's 8th (zero-weight) tap column
+    if ((rc = new_buf(h, "input", h->in_hp, h->in_hp, 4, &h->in_f16))) return rc;
 
     int ci = 0;  // canonical conv cursor
     {
         Op o; o.kind = OP_PRE; o.name = "input"; o.label = "preprocess_rgb8_f16:input";
-        o.bytes_per_img = (double)S * S * (3 + 16);
+        o.bytes_per_img = (double)S * S * (3 + 8);
         h->ops.push_back(o);
     }
     const int H1 = out_dim(S, 7, 2, 3), H2 = out_dim(H1, 3, 2, 1);
     Buf stem, pool;
     if ((rc = new_buf(h, "stem", H1, H1, 64, &stem))) return rc;
     if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
-    h->ops.push_back(conv_op(h, "stem", add_panel(h, { ci++ }), h->in_f16, stem, 2, 3, 1, nullptr));
+    {
+        // the stem reads the physically padded image: pad = 0 there, output geometry from S
+        Op o = conv_op(h, "stem", add_panel(h, { ci++ }), h->in_f16, stem, 2, 0, 1, nullptr);
+        o.P = H1; o.Q = H1;
+        o.flops_per_img = 2.0 * H1 * H1 * 64 * 147.0;
+        o.bytes_per_img = 2.0 * ((double)S * S * 3 + (double)H1 * H1 * 64);
+        h->ops.push_back(o);
+    }
     {
         Op o; o.kind = OP_POOL; o.name = "pool"; o.label = "maxpool3x3s2_f16:pool"; o.in = stem; o.out = pool;
         o.P = H2; o.Q = H2;
@@ -533,7 +542,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
     hipError_t e = hipSuccess;
     switch (o.kind) {
         case OP_PRE:
-            e = launch_preprocess(h->in_u8, h->in_f16.d, (long long)n * h->S * h->S, h->stream);
+            e = launch_preprocess(h->in_u8, h->in_f16.d, n, h->S, h->in_hp, h->in_hp, h->stream);
             break;
         case OP_CONV: {
             ConvParams p;
@@ -631,9 +640,9 @@ int alloc_panels(yh_engine* h) {
         if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * 4))) return rc;
         p.bias = (float*)q;
         if (p.tile == TILE_64x256_SMALLC) {
-            const int nt = p.Kpad / 8;
+            const int nt = p.Kpad / 8, cpr = (p.k + 1) / 2;  // chunks per kernel row
             std::vector<int2> t(nt);
-            for (int i = 0; i < nt; ++i) t[i] = i < p.k * p.k ? make_int2(i / p.k, i % p.k) : make_int2(1 << 20, 0);
+            for (int i = 0; i < nt; ++i) t[i] = i < p.k * cpr ? make_int2(i / cpr, 2 * (i % cpr)) : make_int2(1 << 20, 0);
             if ((rc = dev_alloc(h, &q, sizeof(int2) * nt))) return rc;
             p.rs_table = (int2*)q;
             HIPCHK(h, hipMemcpy(q, t.data(), sizeof(int2) * nt, hipMemcpyHostToDevice));
@@ -671,9 +680,13 @@ int upload_panels(yh_engine* h, const uint8_t* blob) {
             for (int o = 0; o < d.cout; ++o) {
                 uint16_t* dst = w.data() + (size_t)(row0 + o) * p.Kpad;
                 if (p.cin_store == d.cin) memcpy(dst, src + (size_t)o * K, K * 2);
-                else
-                    for (int t = 0; t < d.k * d.k; ++t)
-                        for (int c = 0; c < d.cin; ++c) dst[(size_t)t * p.cin_store + c] = src[(size_t)o * K + (size_t)t * d.cin + c];
+                else {  // stem: chunk (r, j) holds pixels s = 2j, 2j+1 with 4 channels each; s = k and c = 3 are zero
+                    const int cpr = (d.k + 1) / 2;
+                    for (int r = 0; r < d.k; ++r)
+                        for (int sx = 0; sx < d.k; ++sx)
+                            for (int c = 0; c < d.cin; ++c)
+                                dst[(size_t)(r * cpr + sx / 2) * 8 + (sx & 1) * 4 + c] = src[(size_t)o * K + ((size_t)r * d.k + sx) * d.cin + c];
+                }
             }
             memcpy(bias.data() + row0, blob + d.blob_b_off, (size_t)d.cout * 4);
             row0 += d.cout;
@@ -1073,6 +1086,29 @@ int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (div[0] || div[1]) return h->fail(YH_EDIVERGE, "reference flood fill (yolact.rs:57-78) does not terminate on this frame");
     HIPCHK(h, hipMemcpy(frame, h->frame_dev, npx * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nfloats, int32_t dims[4]) {
+    if (!h || !name || !dims) return YH_EINVAL;
+    auto it = h->named.find(name);
+    if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
+    if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
+    const Buf& b = it->second;
+    const int n = h->cur_n;
+    const size_t per = (size_t)b.h * b.w * b.c;
+    dims[0] = n; dims[1] = b.h; dims[2] = b.w; dims[3] = b.c;
+    if (!dst) return YH_OK;
+    if (nfloats < per * n) return h->fail(YH_EINVAL, "destination too small");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = ensure_out_f32(h, per * n);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = launch_f16_to_f32(b.d + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->stream);
+        if (e != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
+    }
+    HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return YH_OK;
 }
 

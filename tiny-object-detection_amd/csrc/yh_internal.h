@@ -56,7 +56,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------
 // Element-wise / gather kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_preprocess(const uint8_t* rgb, half_t* out8, long long npix, hipStream_t s);
+hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int Hp, int Wp, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s);
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
                            long long x_img_stride, long long y_img_stride, hipStream_t s);

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("yh_profile_run", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_time_steps", _i, [_vp, _i, _i, C.POINTER(_f)]),
     ("yh_flops_per_frame", C.c_double, [_vp]),
+    ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     ("yh_op_maxpool3x3s2_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -238,6 +239,14 @@ class Engine:
         sh, sw = src.shape[:2]
         out = np.empty((dh, dw, 3), np.uint8)
         self._chk(self.L.yh_resize_triangle_rgb8(self.h, _p(src), sw, sh, _p(out), dw, dh))
+        return out
+
+    def tensor(self, name):
+        """Named intermediate of the last forward as f32 NHWC (test hook)."""
+        d = (C.c_int32 * 4)()
+        self._chk(self.L.yh_debug_read_tensor(self.h, name.encode(), None, 0, C.byref(d)))
+        out = np.empty(tuple(d), np.float32)
+        self._chk(self.L.yh_debug_read_tensor(self.h, name.encode(), _p(out), out.size, C.byref(d)))
         return out
 
     # ---- measurement hooks
