@@ -100,8 +100,8 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=16):
                        f"f16-storage oracle (OpenMP, {cores} threads), {dt:.1f} s of CPU work")
 
 
-def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4):
-    eng = ya.Engine(input_size=size, backbone=50, max_batch=batch, use_graph=True, device=local_rank)
+def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50):
+    eng = ya.Engine(input_size=size, backbone=backbone, max_batch=batch, use_graph=True, device=local_rank)
     eng.load_weights_device(blob_dev_ptr, blob_nbytes)
     g = torch.Generator(device=f"cuda:{local_rank}")
     start, _ = shard_frames(world * batch, world, rank)
@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (64: configs[2]/[3]; 1: configs[1])")
     ap.add_argument("--size", type=int, default=550)
+    ap.add_argument("--backbone", type=int, default=50, choices=(50, 101), help="50: YOLACT-550 R50 (default); 101 with --size 700: configs[4] geometry in f16")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
@@ -163,7 +164,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     # weights: generated once on rank 0, replicated with ONE RCCL broadcast over xGMI
-    probe = ya.Engine(input_size=a.size, backbone=50, max_batch=1, use_graph=False, device=local_rank)
+    probe = ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=1, use_graph=False, device=local_rank)
     nbytes = probe.weights_nbytes()
     blob = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
     if rank == 0:
@@ -173,14 +174,14 @@ def main():
     torch.cuda.synchronize()
 
     dt, prof, flops, ndet, frame = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
-                                              a.seed, a.size, blob.data_ptr(), nbytes)
+                                              a.seed, a.size, blob.data_ptr(), nbytes, backbone=a.backbone)
     extra = {}
     if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
         s1 = max(a.steps * 4, 40)
         dt1, prof1, _, _, _ = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
-                                         blob.data_ptr(), nbytes)
+                                         blob.data_ptr(), nbytes, backbone=a.backbone)
         if rank == 0:
-            extra["batch1"] = dict(workload=f"YOLACT-550 R50-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
+            extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1))
     if rank != 0:
@@ -189,11 +190,11 @@ def main():
         return
     fps = world * a.batch * a.steps / dt
     line = {
-        "metric": "frames/sec YOLACT-550 (ResNet-50-FPN, 32 prototypes) fp16, forward + detection tail",
+        "metric": f"frames/sec YOLACT-{a.size} (ResNet-{a.backbone}-FPN, 32 prototypes) fp16, forward + detection tail",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"YOLACT-550 R50-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, "
+        "config": {"workload": f"YOLACT-{a.size} R{a.backbone}-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, "
                                f"hipGraph steady state, frames sharded over {world} GPU(s), weights replicated by one RCCL broadcast",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [a.size, a.size, 3],
                    "weights": f"seeded synthetic (seed {a.seed}), BN folded", "detections_first_frames": ndet},

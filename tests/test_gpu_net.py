@@ -199,3 +199,27 @@ def test_errors_are_reported_not_swallowed(built):
     with pytest.raises(ya.YhError):
         eng.load_weights(blob)
     eng.close()
+
+
+def test_resnet101_backbone_and_odd_input_size(built, oracle):
+    """YOLACT-700's backbone family (R101, configs[4]) and a non-multiple-of-32 input (pyramid sizes
+    come from the conv arithmetic, not from S/stride): heads vs oracle, tail bit-exact."""
+    import yolact_amd as ya
+    S2 = 145
+    eng = ya.Engine(input_size=S2, backbone=101, max_batch=1, use_graph=False)
+    blob = eng.generate_weights(seed=3)
+    eng.load_weights(blob)
+    net = oracle.Net(101, S2, 81, blob=blob)
+    assert eng.P == net.P and np.array_equal(eng.priors(), net.priors())
+    img = np.random.default_rng(5).integers(0, 256, (1, S2, S2, 3), dtype=np.uint8)
+    eng.set_input(img)
+    eng.evaluate()
+    got = [eng.output(i) for i in range(4)]
+    want = net.forward(img, f16=True)
+    for name, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
+        assert np.abs(a - b).max() <= 0.04 * max(1.0, np.abs(b).max()), name
+    dets, masks = eng.detections(0)
+    odets, omasks = oracle.detect(got[0][0], got[1][0], got[2][0], got[3][0], net.priors())
+    assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
+    assert np.array_equal(masks, omasks)
+    eng.close()
