@@ -192,6 +192,31 @@ int yh_time_steps(yh_engine* h, int32_t with_tail, int32_t steps, float* ms_tota
 /* Algorithmic conv FLOPs of one frame for this architecture (2 x MAC, convs only). */
 double yh_flops_per_frame(const yh_engine* h);
 
+/* ---- TFLite model path: run the reference's own model family ---------------- */
+/* A user who holds data/FRC_model.tflite (uint8 per-tensor quantised MobileNetV2-FPN YOLACT,
+ * data/README.md:5-16; absent from the checkout) runs it here instead of tflite+EdgeTPU. Supported
+ * builtin ops: the histogram of data/FRC_model_edgetpu.log:7-19 (CONV_2D, DEPTHWISE_CONV_2D, ADD,
+ * PAD, RESIZE_BILINEAR, TANH, RELU, CONCATENATION, RESHAPE, QUANTIZE) plus RELU6 and DEQUANTIZE.
+ * The EdgeTPU-compiled file is one custom op and is rejected with a message naming it. */
+typedef struct yh_tfl yh_tfl;
+/* Parses only (no GPU needed): YH_OK or YH_EWEIGHTS with a message; never reads out of bounds. */
+int yh_tfl_validate(const void* model_bytes, size_t nbytes, int32_t* n_tensors, int32_t* n_ops, char* err, size_t err_cap);
+/* FlatBufferModel::build_from_file + InterpreterBuilder + allocate_tensors (src/yolact.rs:18-35). */
+int yh_tfl_create(const void* model_bytes, size_t nbytes, int32_t device, yh_tfl** out);
+void yh_tfl_destroy(yh_tfl* h);
+const char* yh_tfl_last_error(const yh_tfl* h);
+int yh_tfl_input_info(const yh_tfl* h, yh_tensor_info* info);                 /* inputs()[0], :149-150 */
+int yh_tfl_output_count(const yh_tfl* h);                                      /* outputs(), :166 */
+int yh_tfl_output_info(const yh_tfl* h, int32_t i, yh_tensor_info* info);      /* tensor_info(output), :170-175 */
+int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes);              /* tensor_data_mut copy, :161-162 */
+int yh_tfl_invoke(yh_tfl* h);                                                  /* interpreter.invoke(), :163 */
+int yh_tfl_output_read(yh_tfl* h, int32_t i, void* dst, size_t nbytes);        /* tensor_data::<u8|f32>, :173,:180 */
+int yh_tfl_tensor_count(const yh_tfl* h);
+int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes);   /* test hook: any tensor by index */
+/* Yolact::classify (src/yolact.rs:192-234) with this model in the middle: two S x S tiles, one
+ * invoke each, output 4 dequantised (:177) and post-processed (:90-131), all on device. */
+int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, int32_t height, int32_t compat_mode);
+
 /* Test hook: copies the named intermediate tensor of the last forward (layer names of DESIGN.md:
  * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
  * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. */

@@ -1,0 +1,148 @@
+"""-m gpu: the TFLite model path: reader + quantised executor through the C ABI,
+bit for bit against oracle/tfl_oracle.py on synthetic models (the reference's model file is absent)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tfl_builder as B
+import tfl_models as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(model, x):
+    import tfl_oracle as O
+    import yolact_amd as ya
+    eng = ya.TfliteEngine(B.serialize(model))
+    eng.set_input(x)
+    eng.invoke()
+    val = O.run_model(model, {model.inputs[0]: x})
+    outs = [eng.output(i) for i in range(eng.output_count())]
+    return eng, val, outs
+
+
+CASES = [("CONV_2D", dict()), ("CONV_2D", dict(k=1, stride=1, act=1, ci=16, co=5)), ("CONV_2D", dict(k=3, stride=2, padding=0, act=3, h=11, w=10)),
+         ("CONV_2D", dict(k=3, stride=2, padding=1, h=12, w=9)), ("CONV_2D", dict(k=5, stride=1, padding=1, h=9, w=9, so=0.3)),
+         ("DEPTHWISE_CONV_2D", dict()), ("DEPTHWISE_CONV_2D", dict(stride=2, act=3, h=10, w=11, ci=16)), ("DEPTHWISE_CONV_2D", dict(dm=2, ci=4)),
+         ("ADD", dict()), ("ADD", dict(act=1)), ("PAD", dict()), ("RESIZE_BILINEAR", dict()), ("RESIZE_BILINEAR", dict(hi=7, wi=7, ho=14, wo=14, align_corners=True)),
+         ("RESIZE_BILINEAR", dict(hi=4, wi=6, ho=7, wo=9, half_pixel_centers=True)), ("TANH", dict()), ("RELU", dict()), ("QUANTIZE", dict()),
+         ("CONCATENATION", dict()), ("CONCATENATION", dict(axis=-1)), ("RESHAPE", dict()), ("DEQUANTIZE", dict())]
+
+
+@pytest.mark.parametrize("code,kw", CASES)
+def test_single_op_bit_exact(built, code, kw):
+    rng = np.random.default_rng(hash(code) % 1000 + len(kw))
+    model = M.single_op(code, rng, **kw)
+    x = rng.integers(0, 256, model.tensors[model.inputs[0]].shape, dtype=np.uint8)
+    eng, val, outs = _run_both(model, x)
+    want = val[model.outputs[0]]
+    assert outs[0].shape == want.shape and outs[0].dtype == want.dtype
+    assert np.array_equal(outs[0], want)
+    eng.close()
+
+
+def test_known_answers_dequantize_and_saturation(built):
+    """SURVEY Appendix A.5 through the model path; conv saturation at both clamp ends."""
+    rng = np.random.default_rng(0)
+    m = M.single_op("DEQUANTIZE", rng)
+    x = np.zeros(m.tensors[0].shape, np.uint8)
+    x.flat[0], x.flat[1] = 130, 0
+    m.tensors[0].scale, m.tensors[0].zp = 0.5, 128
+    eng, val, outs = _run_both(m, x)
+    assert outs[0].flat[0] == 1.0 and outs[0].flat[1] == -64.0
+    eng.close()
+    m = M.single_op("CONV_2D", rng, so=0.0005)      # tiny output scale: everything saturates
+    x = rng.integers(0, 256, m.tensors[0].shape, dtype=np.uint8)
+    eng, val, outs = _run_both(m, x)
+    assert np.array_equal(outs[0], val[m.outputs[0]])
+    assert np.isin(outs[0], (0, 255)).mean() > 0.9     # both clamp ends are exercised
+    eng.close()
+
+
+def test_mobilenet_like_graph_every_tensor(built):
+    """Every activation of a 40-op MobileNetV2-FPN-shaped graph, not only the outputs."""
+    rng = np.random.default_rng(7)
+    model = M.mobilenet_like(rng, S=64, C=6)
+    x = rng.integers(0, 256, (1, 64, 64, 3), dtype=np.uint8)
+    eng, val, outs = _run_both(model, x)
+    assert eng.output_count() == 5
+    info = eng.output_info(4)
+    assert info["dims"] == (1, 64, 6) and info["kind"] == 3 and info["scale"] == 0.0078125 and info["zero_point"] == 128
+    written = {o for op in model.ops for o in op.outputs}
+    for i in sorted(written):
+        t = model.tensors[i]
+        got = eng.tensor(i, t.shape, B.NP_TYPE[t.dtype])
+        assert np.array_equal(got, val[i]), (i, t.name)
+    for k, o in enumerate(model.outputs):
+        assert np.array_equal(outs[k], val[o])
+    assert len(np.unique(outs[4])) > 8               # not a degenerate constant output
+    eng.close()
+
+
+def test_classify_through_a_tflite_model(built, oracle, golden_dir):
+    """Yolact::classify (yolact.rs:192-234) with a .tflite in the middle: pre-processing, two
+    invokes, output-4 dequantisation (yolact.rs:177), postprocess, stitch, resize back."""
+    from PIL import Image
+    import tfl_oracle as O
+    import yolact_amd as ya
+    rng = np.random.default_rng(11)
+    S, C = 64, 6
+    model = M.mobilenet_like(rng, S=S, C=C)
+    eng = ya.TfliteEngine(B.serialize(model))
+    rgb = np.asarray(Image.open(os.path.join(golden_dir, "frc_balls.png")).convert("RGB").resize((160, 120), Image.BILINEAR))
+    frame0 = oracle.pack_rgb(rgb)
+    tiles = oracle.classify_pre(frame0, 160, 120, S)
+    cells = []
+    for t in range(2):
+        val = O.run_model(model, {model.inputs[0]: tiles[t:t + 1]})
+        q = val[model.outputs[4]]
+        cells.append(oracle.dequant_u8(q.reshape(-1), 0.0078125, 128).reshape(S // 8 * (S // 8), C))
+    cells = np.stack(cells)
+    for mode in (ya.COMPAT_SANE, ya.COMPAT_STRICT):
+        rc, want = oracle.classify_post(cells, S, C, mode, 160, 120)
+        frame = frame0.copy()
+        if rc:
+            with pytest.raises(ya.YhError) as e:
+                eng.classify_frame(frame, 160, 120, mode)
+            assert e.value.code == ya.EDIVERGE and np.array_equal(frame, frame0)
+        else:
+            eng.classify_frame(frame, 160, 120, mode)
+            assert np.array_equal(frame, want)
+    eng.close()
+
+
+def test_unsupported_models_are_rejected_with_a_reason(built):
+    import yolact_amd as ya
+    rng = np.random.default_rng(3)
+    m = M.single_op("CONV_2D", rng)
+    m.tensors[1].scale = None                          # weights without quantisation parameters
+    with pytest.raises(ya.YhError) as e:
+        ya.TfliteEngine(B.serialize(m))
+    assert "uint8" in str(e.value)
+    with pytest.raises(ya.YhError):
+        ya.TfliteEngine(b"not a flatbuffer at all.....")
+    m = M.single_op("ADD", rng)
+    eng = ya.TfliteEngine(B.serialize(m))
+    with pytest.raises(ya.YhError):
+        eng.set_input(np.zeros(3, np.uint8))           # wrong size is an error here (the reference only warns, yolact.rs:151-158)
+    eng.close()
+
+
+def test_yolact_init_from_model_file(built, oracle, tmp_path, golden_dir):
+    """`Yolact::init()` with a model file on disk, as the reference loads one (yolact.rs:18-20)."""
+    from PIL import Image
+    import yolact_amd as ya
+    rng = np.random.default_rng(5)
+    path = tmp_path / "FRC_model.tflite"
+    path.write_bytes(B.serialize(M.mobilenet_like(rng, S=64, C=6)))
+    y = ya.Yolact.init(model_path=str(path), compat_mode=ya.COMPAT_SANE)
+    rgb = np.asarray(Image.open(os.path.join(golden_dir, "red_robot.png")).convert("RGB").resize((640, 480), Image.BILINEAR))
+    buf = oracle.pack_rgb(rgb)
+    y.classify(buf)
+    assert ((buf >> 24) <= 3).all() and (buf & 0xFFFF == 0).all()
+    with pytest.raises(FileNotFoundError):
+        ya.Yolact.init(model_path=str(tmp_path / "missing.tflite"))
+    y.interpreter.close()

@@ -1,0 +1,564 @@
+// tflite_exec.hip — executes a parsed TFLite model (uint8 per-tensor quantised MobileNetV2-style
+// graphs: the reference's FRC_model.tflite family, data/README.md:5-16) on the GPU.
+//
+// SURVEY.md §8f-1. Replaces, for a user who holds the reference's model file, the whole of
+// interpreter.invoke() (/root/reference/src/yolact.rs:163) plus the surrounding classify
+// (:192-234). The arithmetic restates TensorFlow Lite's published uint8 reference kernels
+// (gemmlowp fixed-point requantisation); the runtime itself is the un-vendored tflite 0.9.0 crate
+// (Cargo.lock:1106-1108), so parity with it is UNPINNED; tests check this executor bit for bit
+// against oracle/tfl_oracle.py on synthetic models.
+//
+// These are HBM/latency-bound byte kernels on small tensors (a 224x224 MobileNetV2 is ~0.3 GMAC):
+// one lane per output element, output channel fastest (coalesced NHWC stores, broadcast input
+// reads), int32 accumulation. They are deliberately NOT reshaped into MFMA GEMMs.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tflite_model.h"
+#include "yh_internal.h"
+
+using namespace yh;
+
+namespace {
+
+__device__ __forceinline__ int q_srdhm(int a, int b) {
+    if (a == INT_MIN && b == INT_MIN) return INT_MAX;
+    const long long ab = (long long)a * (long long)b;
+    const long long nudge = ab >= 0 ? (1ll << 30) : (1ll - (1ll << 30));
+    return (int)((ab + nudge) / (1ll << 31));
+}
+__device__ __forceinline__ int q_rdbpot(int x, int e) {
+    if (e == 0) return x;
+    const int mask = (1 << e) - 1, rem = x & mask, thr = (mask >> 1) + (x < 0 ? 1 : 0);
+    return (x >> e) + (rem > thr ? 1 : 0);
+}
+__device__ __forceinline__ int q_mbqm(int x, int m, int shift) {
+    const int left = shift > 0 ? shift : 0, right = shift > 0 ? 0 : -shift;
+    return q_rdbpot(q_srdhm(x * (1 << left), m), right);
+}
+__device__ __forceinline__ int q_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct ConvQ {
+    const uint8_t *x, *w; const int* bias; uint8_t* y;
+    int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, dm;
+    int zx, zw, zo, mult, shift, lo, hi;
+};
+
+__global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.Ho * p.Wo * p.Co) return;
+    const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo;
+    int acc = 0;
+    for (int r = 0; r < p.kh; ++r) {
+        const int iy = oy * p.sh - p.ph + r * p.dh;
+        if ((unsigned)iy >= (unsigned)p.H) continue;
+        for (int s = 0; s < p.kw; ++s) {
+            const int ix = ox * p.sw - p.pw + s * p.dw;
+            if ((unsigned)ix >= (unsigned)p.W) continue;
+            const uint8_t* xp = p.x + ((size_t)iy * p.W + ix) * p.Ci;
+            const uint8_t* wp = p.w + (((size_t)oc * p.kh + r) * p.kw + s) * p.Ci;
+            for (int c = 0; c < p.Ci; ++c) acc += ((int)xp[c] - p.zx) * ((int)wp[c] - p.zw);
+        }
+    }
+    acc += p.bias ? p.bias[oc] : 0;
+    p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
+}
+
+__global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.Ho * p.Wo * p.Co) return;
+    const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo, ic = oc / p.dm;
+    int acc = 0;
+    for (int r = 0; r < p.kh; ++r) {
+        const int iy = oy * p.sh - p.ph + r * p.dh;
+        if ((unsigned)iy >= (unsigned)p.H) continue;
+        for (int s = 0; s < p.kw; ++s) {
+            const int ix = ox * p.sw - p.pw + s * p.dw;
+            if ((unsigned)ix >= (unsigned)p.W) continue;
+            acc += ((int)p.x[((size_t)iy * p.W + ix) * p.Ci + ic] - p.zx) * ((int)p.w[((size_t)r * p.kw + s) * p.Co + oc] - p.zw);
+        }
+    }
+    acc += p.bias ? p.bias[oc] : 0;
+    p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
+}
+
+struct AddQ { const uint8_t *a, *b; uint8_t* y; long long n; int za, zb, zo, m1, s1, m2, s2, mo, so, lo, hi; };
+__global__ __launch_bounds__(256) void tfl_add_u8(const AddQ p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n) return;
+    const int v1 = q_mbqm(((int)p.a[t] - p.za) * (1 << 20), p.m1, p.s1);
+    const int v2 = q_mbqm(((int)p.b[t] - p.zb) * (1 << 20), p.m2, p.s2);
+    p.y[t] = (uint8_t)q_clamp(q_mbqm(v1 + v2, p.mo, p.so) + p.zo, p.lo, p.hi);
+}
+
+// requantise (QUANTIZE u8->u8, RELU/RELU6) : clamp(mbqm(q - zi) + zo, lo, hi)
+__global__ __launch_bounds__(256) void tfl_requant_u8(const uint8_t* x, uint8_t* y, long long n, int zi, int zo, int m, int s, int lo, int hi) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) y[t] = (uint8_t)q_clamp(q_mbqm((int)x[t] - zi, m, s) + zo, lo, hi);
+}
+__global__ __launch_bounds__(256) void tfl_quantize_f32(const float* x, uint8_t* y, long long n, float scale, int zo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float v = __fdiv_rn(x[t], scale);
+    const float r = v >= 0.0f ? floorf(__fadd_rn(v, 0.5f)) : ceilf(__fsub_rn(v, 0.5f));
+    y[t] = (uint8_t)q_clamp((int)r + zo, 0, 255);
+}
+__global__ __launch_bounds__(256) void tfl_dequantize_u8(const uint8_t* x, float* y, long long n, float scale, int z) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) y[t] = __fmul_rn(scale, (float)((int)x[t] - z));   // yolact.rs:177
+}
+__global__ __launch_bounds__(256) void tfl_lut_u8(const uint8_t* x, uint8_t* y, long long n, const uint8_t* lut) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) y[t] = lut[x[t]];
+}
+struct PadQ { const uint8_t* x; uint8_t* y; int id[4], od[4], before[4]; int fill; };
+__global__ __launch_bounds__(256) void tfl_pad_u8(const PadQ p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)p.od[0] * p.od[1] * p.od[2] * p.od[3];
+    if (t >= n) return;
+    int c[4];
+    long long r = t;
+    for (int d = 3; d >= 0; --d) { c[d] = (int)(r % p.od[d]) - p.before[d]; r /= p.od[d]; }
+    bool in = true;
+    for (int d = 0; d < 4; ++d) in = in && (unsigned)c[d] < (unsigned)p.id[d];
+    p.y[t] = in ? p.x[(((long long)c[0] * p.id[1] + c[1]) * p.id[2] + c[2]) * p.id[3] + c[3]] : (uint8_t)p.fill;
+}
+struct ResizeQ { const uint8_t* x; uint8_t* y; int H, W, C, Ho, Wo; float hs, ws; int half_pixel; };
+__global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(const ResizeQ p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.Ho * p.Wo * p.C) return;
+    const int c = t % p.C, r0 = t / p.C, ox = r0 % p.Wo, oy = r0 / p.Wo;
+    const float iy = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)oy, 0.5f), p.hs), 0.5f) : __fmul_rn((float)oy, p.hs);
+    const float ix = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)ox, 0.5f), p.ws), 0.5f) : __fmul_rn((float)ox, p.ws);
+    int y0 = (int)floorf(iy), y1 = (int)ceilf(iy), x0 = (int)floorf(ix), x1 = (int)ceilf(ix);
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > p.H - 1 ? p.H - 1 : y1; x1 = x1 > p.W - 1 ? p.W - 1 : x1;
+    const float fy = __fsub_rn(iy, (float)y0), fx = __fsub_rn(ix, (float)x0);
+    const float gy = __fsub_rn(1.0f, fy), gx = __fsub_rn(1.0f, fx);
+    auto at = [&](int yy, int xx) { return (float)p.x[((size_t)yy * p.W + xx) * p.C + c]; };
+    float v = __fmul_rn(__fmul_rn(at(y0, x0), gy), gx);
+    v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y1, x0), fy), gx));
+    v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y0, x1), gy), fx));
+    v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y1, x1), fy), fx));
+    const float r = floorf(__fadd_rn(v, 0.5f));
+    p.y[t] = (uint8_t)(r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r));
+}
+// copy one concat input [outer][inner] into the output at column `off` of rows of `row` elements
+struct CatQ { const uint8_t* x; uint8_t* y; long long outer; int inner, row, off, esz; int rescale; float sc, bias; int zo; };
+__global__ __launch_bounds__(256) void tfl_concat_part(const CatQ p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.outer * p.inner * p.esz) return;
+    const long long e = t / p.esz;
+    const int b = (int)(t - e * p.esz);
+    const long long o = e / p.inner;
+    const int i = (int)(e - o * p.inner);
+    const long long dst = ((o * p.row) + p.off + i) * p.esz + b;
+    if (p.rescale) {
+        const float v = __fadd_rn(__fmul_rn((float)p.x[t], p.sc), p.bias);
+        const float r = v >= 0.0f ? floorf(__fadd_rn(v, 0.5f)) : ceilf(__fsub_rn(v, 0.5f));
+        p.y[dst] = (uint8_t)q_clamp((int)r + p.zo, 0, 255);
+    } else p.y[dst] = p.x[t];
+}
+
+// ---- host-side quantisation helpers (tflite::QuantizeMultiplier etc.)
+void quantize_multiplier(double m, int* mult, int* shift) {
+    if (m == 0.0) { *mult = 0; *shift = 0; return; }
+    int e;
+    const double q = frexp(m, &e);
+    long long qf = (long long)floor(q * (double)(1ll << 31) + 0.5);
+    if (qf == (1ll << 31)) { qf /= 2; ++e; }
+    if (e < -31) { e = 0; qf = 0; }
+    *mult = (int)qf; *shift = e;
+}
+void act_range(int act, float scale, int zp, int* lo, int* hi) {
+    auto q = [&](float v) { const float d = v / scale; return zp + (int)(d >= 0 ? floorf(d + 0.5f) : ceilf(d - 0.5f)); };
+    *lo = 0; *hi = 255;
+    if (act == 1) { *lo = q(0.0f) > 0 ? q(0.0f) : 0; }
+    else if (act == 3) { *lo = q(0.0f) > 0 ? q(0.0f) : 0; *hi = q(6.0f) < 255 ? q(6.0f) : 255; }
+    else if (act == 2) { *lo = q(-1.0f) > 0 ? q(-1.0f) : 0; *hi = q(1.0f) < 255 ? q(1.0f) : 255; }
+}
+void same_pad(int in, int k, int stride, int dil, int* out, int* before) {
+    *out = (in + stride - 1) / stride;
+    const int eff = (k - 1) * dil + 1, total = (*out - 1) * stride + eff - in;
+    *before = total > 0 ? total / 2 : 0;
+}
+
+enum PKind { P_CONV, P_DW, P_ADD, P_REQUANT, P_QUANT_F32, P_DEQUANT, P_LUT, P_PAD, P_RESIZE, P_CONCAT, P_COPY };
+struct Prepared {
+    PKind kind;
+    ConvQ conv; AddQ add; PadQ pad; ResizeQ rs;
+    std::vector<CatQ> cat;
+    const void* src = nullptr; void* dst = nullptr; long long n = 0;
+    int zi = 0, zo = 0, m = 0, s = 0, lo = 0, hi = 255; float scale = 1.0f;
+    const uint8_t* lut = nullptr;
+};
+
+}  // namespace
+
+struct yh_tfl {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<uint8_t> file;
+    TflModel m;
+    std::vector<void*> tens;
+    std::vector<void*> extra;   // LUTs etc.
+    std::vector<Prepared> plan;
+    // classify scratch
+    uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
+    uint8_t* tiles_dev = nullptr;
+    float *rs_tmp = nullptr, *cells_dev = nullptr;
+    int* diverged_dev = nullptr;
+    size_t frame_cap = 0, rs_cap = 0;
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+namespace {
+thread_local std::string g_tfl_create_error;
+
+#define TCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (h)->fail(YH_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+int prepare(yh_tfl* h) {
+    TflModel& m = h->m;
+    h->tens.assign(m.tensors.size(), nullptr);
+    for (size_t i = 0; i < m.tensors.size(); ++i) {
+        const TflTensor& t = m.tensors[i];
+        const size_t bytes = t.count() * t.elem();
+        if (bytes == 0) continue;
+        TCHK(h, hipMalloc(&h->tens[i], bytes + 16));
+        if (t.data) TCHK(h, hipMemcpy(h->tens[i], t.data, bytes, hipMemcpyHostToDevice));
+        else TCHK(h, hipMemset(h->tens[i], 0, bytes));
+    }
+    auto T = [&](int i) -> const TflTensor& { return m.tensors[i]; };
+    auto need = [&](bool c, const std::string& what) { if (!c && h->err.empty()) h->err = what; return c; };
+    for (size_t oi = 0; oi < m.ops.size(); ++oi) {
+        const TflOp& op = m.ops[oi];
+        const std::string at = " (operator " + std::to_string(oi) + ")";
+        Prepared pr;
+        auto u8 = [&](int i) { return T(i).type == TFL_U8 && T(i).quant; };
+        switch (op.code) {
+            case TFL_CONV_2D:
+            case TFL_DEPTHWISE_CONV_2D: {
+                if (!need(op.in.size() >= 2 && op.out.size() == 1, "conv: bad arity" + at)) return YH_EINVAL;
+                const TflTensor &x = T(op.in[0]), &w = T(op.in[1]), &y = T(op.out[0]);
+                const bool dw = op.code == TFL_DEPTHWISE_CONV_2D;
+                const int bi = op.in.size() > 2 ? op.in[2] : -1;
+                if (!need(u8(op.in[0]) && u8(op.in[1]) && u8(op.out[0]) && x.shape.size() == 4 && w.shape.size() == 4 && y.shape.size() == 4 &&
+                          x.shape[0] == 1 && (bi < 0 || (T(bi).type == TFL_I32 && T(bi).data)) && w.data,
+                          "conv: only uint8 per-tensor quantised NHWC batch-1 convolutions with constant weights are supported" + at)) return YH_EINVAL;
+                ConvQ& c = pr.conv;
+                c.H = x.shape[1]; c.W = x.shape[2]; c.Ci = x.shape[3];
+                c.kh = w.shape[1]; c.kw = w.shape[2];
+                c.Co = dw ? w.shape[3] : w.shape[0];
+                c.dm = dw ? op.depth_mult : 1;
+                c.sh = op.stride_h; c.sw = op.stride_w; c.dh = op.dil_h; c.dw = op.dil_w;
+                if (op.padding == 0) { same_pad(c.H, c.kh, c.sh, c.dh, &c.Ho, &c.ph); same_pad(c.W, c.kw, c.sw, c.dw, &c.Wo, &c.pw); }
+                else { c.Ho = (c.H - ((c.kh - 1) * c.dh + 1) + c.sh) / c.sh; c.Wo = (c.W - ((c.kw - 1) * c.dw + 1) + c.sw) / c.sw; c.ph = c.pw = 0; }
+                if (!need(y.shape[1] == c.Ho && y.shape[2] == c.Wo && y.shape[3] == c.Co && (dw ? (w.shape[0] == 1 && c.Co == c.Ci * c.dm) : w.shape[3] == c.Ci) &&
+                          (bi < 0 || (int)T(bi).count() == c.Co), "conv: tensor shapes are inconsistent" + at)) return YH_EINVAL;
+                c.x = (const uint8_t*)h->tens[op.in[0]]; c.w = (const uint8_t*)h->tens[op.in[1]];
+                c.bias = bi >= 0 ? (const int*)h->tens[bi] : nullptr; c.y = (uint8_t*)h->tens[op.out[0]];
+                c.zx = x.zp; c.zw = w.zp; c.zo = y.zp;
+                quantize_multiplier((double)x.scale * (double)w.scale / (double)y.scale, &c.mult, &c.shift);
+                act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
+                pr.kind = dw ? P_DW : P_CONV;
+                break;
+            }
+            case TFL_ADD: {
+                if (!need(op.in.size() == 2 && u8(op.in[0]) && u8(op.in[1]) && u8(op.out[0]) && T(op.in[0]).count() == T(op.out[0]).count() &&
+                          T(op.in[1]).count() == T(op.out[0]).count(), "add: only same-shape uint8 tensors are supported" + at)) return YH_EINVAL;
+                const TflTensor &a = T(op.in[0]), &b = T(op.in[1]), &y = T(op.out[0]);
+                AddQ& q = pr.add;
+                q.a = (const uint8_t*)h->tens[op.in[0]]; q.b = (const uint8_t*)h->tens[op.in[1]]; q.y = (uint8_t*)h->tens[op.out[0]];
+                q.n = (long long)y.count(); q.za = a.zp; q.zb = b.zp; q.zo = y.zp;
+                const double twice = 2.0 * (a.scale > b.scale ? (double)a.scale : (double)b.scale);
+                quantize_multiplier((double)a.scale / twice, &q.m1, &q.s1);
+                quantize_multiplier((double)b.scale / twice, &q.m2, &q.s2);
+                quantize_multiplier(twice / ((double)(1 << 20) * (double)y.scale), &q.mo, &q.so);
+                act_range(op.act, y.scale, y.zp, &q.lo, &q.hi);
+                pr.kind = P_ADD;
+                break;
+            }
+            case TFL_RELU:
+            case TFL_RELU6:
+            case TFL_QUANTIZE: {
+                if (!need(op.in.size() == 1 && op.out.size() == 1 && u8(op.out[0]) && T(op.in[0]).count() == T(op.out[0]).count(), "quantize/relu: bad tensors" + at)) return YH_EINVAL;
+                const TflTensor &x = T(op.in[0]), &y = T(op.out[0]);
+                pr.src = h->tens[op.in[0]]; pr.dst = h->tens[op.out[0]]; pr.n = (long long)y.count();
+                if (x.type == TFL_F32 && op.code == TFL_QUANTIZE) { pr.kind = P_QUANT_F32; pr.scale = y.scale; pr.zo = y.zp; break; }
+                if (!need(u8(op.in[0]), "quantize/relu: input must be float32 or quantised uint8" + at)) return YH_EINVAL;
+                pr.kind = P_REQUANT; pr.zi = x.zp; pr.zo = y.zp;
+                quantize_multiplier((double)x.scale / (double)y.scale, &pr.m, &pr.s);
+                act_range(op.code == TFL_RELU ? 1 : (op.code == TFL_RELU6 ? 3 : 0), y.scale, y.zp, &pr.lo, &pr.hi);
+                break;
+            }
+            case TFL_DEQUANTIZE: {
+                if (!need(op.in.size() == 1 && u8(op.in[0]) && T(op.out[0]).type == TFL_F32 && T(op.in[0]).count() == T(op.out[0]).count(), "dequantize: bad tensors" + at)) return YH_EINVAL;
+                pr.kind = P_DEQUANT; pr.src = h->tens[op.in[0]]; pr.dst = h->tens[op.out[0]]; pr.n = (long long)T(op.out[0]).count();
+                pr.scale = T(op.in[0]).scale; pr.zi = T(op.in[0]).zp;
+                break;
+            }
+            case TFL_TANH: {
+                if (!need(op.in.size() == 1 && u8(op.in[0]) && u8(op.out[0]) && T(op.in[0]).count() == T(op.out[0]).count(), "tanh: only uint8 is supported" + at)) return YH_EINVAL;
+                const TflTensor &x = T(op.in[0]), &y = T(op.out[0]);
+                uint8_t lut[256];
+                const float inv = 1.0f / y.scale;
+                for (int q = 0; q < 256; ++q) {   // PopulateLookupTable<uint8_t>
+                    const float xv = x.scale * (float)(q - x.zp);
+                    const float yv = (float)tanh((double)xv);
+                    const float r = yv * inv;
+                    const int rr = (int)(r >= 0 ? floorf(r + 0.5f) : ceilf(r - 0.5f)) + y.zp;
+                    lut[q] = (uint8_t)(rr < 0 ? 0 : (rr > 255 ? 255 : rr));
+                }
+                void* d = nullptr;
+                TCHK(h, hipMalloc(&d, 256));
+                h->extra.push_back(d);
+                TCHK(h, hipMemcpy(d, lut, 256, hipMemcpyHostToDevice));
+                pr.kind = P_LUT; pr.lut = (const uint8_t*)d; pr.src = h->tens[op.in[0]]; pr.dst = h->tens[op.out[0]]; pr.n = (long long)y.count();
+                break;
+            }
+            case TFL_PAD: {
+                if (!need(op.in.size() == 2 && u8(op.in[0]) && u8(op.out[0]) && T(op.in[1]).type == TFL_I32 && T(op.in[1]).data &&
+                          T(op.in[0]).shape.size() == 4 && T(op.in[1]).count() == 8, "pad: need a uint8 4-D input and constant [4,2] paddings" + at)) return YH_EINVAL;
+                const TflTensor &x = T(op.in[0]), &y = T(op.out[0]);
+                const int* pp = (const int*)T(op.in[1]).data;
+                PadQ& q = pr.pad;
+                for (int d = 0; d < 4; ++d) {
+                    q.id[d] = x.shape[d]; q.before[d] = pp[2 * d]; q.od[d] = x.shape[d] + pp[2 * d] + pp[2 * d + 1];
+                    if (!need(pp[2 * d] >= 0 && pp[2 * d + 1] >= 0 && y.shape[d] == q.od[d], "pad: output shape mismatch" + at)) return YH_EINVAL;
+                }
+                q.x = (const uint8_t*)h->tens[op.in[0]]; q.y = (uint8_t*)h->tens[op.out[0]]; q.fill = y.zp;
+                pr.kind = P_PAD;
+                break;
+            }
+            case TFL_RESIZE_BILINEAR: {
+                if (!need(op.in.size() == 2 && u8(op.in[0]) && u8(op.out[0]) && T(op.in[1]).type == TFL_I32 && T(op.in[1]).data && T(op.in[1]).count() == 2 &&
+                          T(op.in[0]).shape.size() == 4 && T(op.in[0]).shape[0] == 1, "resize_bilinear: need uint8 NHWC batch 1 and a constant size" + at)) return YH_EINVAL;
+                const TflTensor &x = T(op.in[0]), &y = T(op.out[0]);
+                const int* sz = (const int*)T(op.in[1]).data;
+                ResizeQ& q = pr.rs;
+                q.H = x.shape[1]; q.W = x.shape[2]; q.C = x.shape[3]; q.Ho = sz[0]; q.Wo = sz[1]; q.half_pixel = op.half_pixel ? 1 : 0;
+                if (!need(y.shape[1] == q.Ho && y.shape[2] == q.Wo && y.shape[3] == q.C, "resize_bilinear: output shape mismatch" + at)) return YH_EINVAL;
+                q.hs = (op.align_corners && q.Ho > 1) ? (float)(q.H - 1) / (float)(q.Ho - 1) : (float)q.H / (float)q.Ho;
+                q.ws = (op.align_corners && q.Wo > 1) ? (float)(q.W - 1) / (float)(q.Wo - 1) : (float)q.W / (float)q.Wo;
+                q.x = (const uint8_t*)h->tens[op.in[0]]; q.y = (uint8_t*)h->tens[op.out[0]];
+                pr.kind = P_RESIZE;
+                break;
+            }
+            case TFL_CONCATENATION: {
+                const TflTensor& y = T(op.out[0]);
+                const int nd = (int)y.shape.size();
+                const int axis = op.axis < 0 ? op.axis + nd : op.axis;
+                if (!need(axis >= 0 && axis < nd && !op.in.empty(), "concatenation: bad axis" + at)) return YH_EINVAL;
+                long long outer = 1; int inner_o = 1;
+                for (int d = 0; d < axis; ++d) outer *= y.shape[d];
+                for (int d = axis; d < nd; ++d) inner_o *= y.shape[d];
+                int off = 0;
+                for (int ii : op.in) {
+                    const TflTensor& x = T(ii);
+                    if (!need(x.type == y.type && (int)x.shape.size() == nd, "concatenation: type/rank mismatch" + at)) return YH_EINVAL;
+                    int inner = 1;
+                    for (int d = axis; d < nd; ++d) inner *= x.shape[d];
+                    CatQ c;
+                    c.x = (const uint8_t*)h->tens[ii]; c.y = (uint8_t*)h->tens[op.out[0]]; c.outer = outer; c.inner = inner; c.row = inner_o; c.off = off;
+                    c.esz = x.type == TFL_U8 ? 1 : 4; c.rescale = 0; c.sc = 1.0f; c.bias = 0.0f; c.zo = y.zp;
+                    if (x.type == TFL_U8 && y.quant && (x.zp != y.zp || x.scale != y.scale)) {  // ConcatenationWithScaling
+                        const float inv = 1.0f / y.scale;
+                        c.rescale = 1; c.sc = x.scale * inv; c.bias = (float)(-x.zp) * c.sc;
+                    }
+                    pr.cat.push_back(c);
+                    off += inner;
+                }
+                if (!need(off == inner_o, "concatenation: output shape mismatch" + at)) return YH_EINVAL;
+                pr.kind = P_CONCAT;
+                break;
+            }
+            case TFL_RESHAPE: {
+                if (!need(!op.in.empty() && T(op.in[0]).count() * T(op.in[0]).elem() == T(op.out[0]).count() * T(op.out[0]).elem(), "reshape: size mismatch" + at)) return YH_EINVAL;
+                pr.kind = P_COPY; pr.src = h->tens[op.in[0]]; pr.dst = h->tens[op.out[0]]; pr.n = (long long)(T(op.out[0]).count() * T(op.out[0]).elem());
+                break;
+            }
+            default:
+                h->err = op.code == TFL_CUSTOM
+                             ? "custom operator '" + op.custom + "' (an EdgeTPU-compiled model? load the non-compiled FRC_model.tflite instead)" + at
+                             : "unsupported builtin operator code " + std::to_string(op.code) + at;
+                return YH_EINVAL;
+        }
+        h->plan.push_back(pr);
+    }
+    return YH_OK;
+}
+
+int run_plan(yh_tfl* h) {
+    hipStream_t s = h->stream;
+    for (const Prepared& p : h->plan) {
+        switch (p.kind) {
+            case P_CONV: hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv); break;
+            case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv); break;
+            case P_ADD: hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(p.add.n)), dim3(256), 0, s, p.add); break;
+            case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
+            case P_QUANT_F32: hipLaunchKernelGGL(tfl_quantize_f32, dim3(nblk(p.n)), dim3(256), 0, s, (const float*)p.src, (uint8_t*)p.dst, p.n, p.scale, p.zo); break;
+            case P_DEQUANT: hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (float*)p.dst, p.n, p.scale, p.zi); break;
+            case P_LUT: hipLaunchKernelGGL(tfl_lut_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n, p.lut); break;
+            case P_PAD: hipLaunchKernelGGL(tfl_pad_u8, dim3(nblk((long long)p.pad.od[0] * p.pad.od[1] * p.pad.od[2] * p.pad.od[3])), dim3(256), 0, s, p.pad); break;
+            case P_RESIZE: hipLaunchKernelGGL(tfl_resize_bilinear_u8, dim3(nblk((long long)p.rs.Ho * p.rs.Wo * p.rs.C)), dim3(256), 0, s, p.rs); break;
+            case P_CONCAT: for (const CatQ& c : p.cat) hipLaunchKernelGGL(tfl_concat_part, dim3(nblk(c.outer * c.inner * c.esz)), dim3(256), 0, s, c); break;
+            case P_COPY: if (hipMemcpyAsync(p.dst, p.src, (size_t)p.n, hipMemcpyDeviceToDevice, s) != hipSuccess) return h->fail(YH_EHIP, "reshape copy failed"); break;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("tflite plan launch: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+void fill_info(const TflTensor& t, yh_tensor_info* info) {
+    info->name = t.name.c_str();
+    info->kind = t.type == TFL_U8 ? YH_KIND_U8 : (t.type == TFL_F32 ? YH_KIND_F32 : t.type);
+    info->ndims = (int)(t.shape.size() < 4 ? t.shape.size() : 4);
+    for (int d = 0; d < 4; ++d) info->dims[d] = d < (int)t.shape.size() ? t.shape[d] : 1;
+    info->scale = t.scale; info->zero_point = t.zp;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_tfl_validate(const void* model_bytes, size_t nbytes, int32_t* n_tensors, int32_t* n_ops, char* err, size_t err_cap) {
+    if (!model_bytes) return YH_EINVAL;
+    TflModel m;
+    const bool ok = m.parse((const uint8_t*)model_bytes, nbytes);
+    if (n_tensors) *n_tensors = (int32_t)m.tensors.size();
+    if (n_ops) *n_ops = (int32_t)m.ops.size();
+    if (err && err_cap) { strncpy(err, m.error.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    return ok ? YH_OK : YH_EWEIGHTS;
+}
+
+const char* yh_tfl_last_error(const yh_tfl* h) { return h ? h->err.c_str() : g_tfl_create_error.c_str(); }
+
+int yh_tfl_create(const void* model_bytes, size_t nbytes, int32_t device, yh_tfl** out) {
+    if (!model_bytes || !out) { g_tfl_create_error = "null argument"; return YH_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_tfl_create_error = "no such HIP device (no CPU fallback)"; return YH_EHIP; }
+    yh_tfl* h = new yh_tfl();
+    h->dev = device;
+    h->file.assign((const uint8_t*)model_bytes, (const uint8_t*)model_bytes + nbytes);
+    auto bail = [&](int rc) { g_tfl_create_error = h->err; yh_tfl_destroy(h); return rc; };
+    if (!h->m.parse(h->file.data(), h->file.size())) { h->err = "tflite parse: " + h->m.error; return bail(YH_EWEIGHTS); }
+    if (h->m.inputs.size() != 1) { h->err = "expected exactly one graph input"; return bail(YH_EINVAL); }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "device setup failed"; return bail(YH_EHIP); }
+    int rc = prepare(h);
+    if (rc) return bail(rc);
+    *out = h;
+    return YH_OK;
+}
+
+void yh_tfl_destroy(yh_tfl* h) {
+    if (!h) return;
+    hipSetDevice(h->dev);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->tens) if (p) hipFree(p);
+    for (void* p : h->extra) hipFree(p);
+    void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };
+    for (void* p : scratch) if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int yh_tfl_input_info(const yh_tfl* h, yh_tensor_info* info) {
+    if (!h || !info) return YH_EINVAL;
+    fill_info(h->m.tensors[h->m.inputs[0]], info);
+    return YH_OK;
+}
+int yh_tfl_output_count(const yh_tfl* h) { return h ? (int)h->m.outputs.size() : YH_EINVAL; }
+int yh_tfl_output_info(const yh_tfl* h, int32_t i, yh_tensor_info* info) {
+    if (!h || !info || i < 0 || i >= (int)h->m.outputs.size()) return YH_EINVAL;
+    fill_info(h->m.tensors[h->m.outputs[i]], info);
+    return YH_OK;
+}
+int yh_tfl_tensor_count(const yh_tfl* h) { return h ? (int)h->m.tensors.size() : YH_EINVAL; }
+
+int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes) {
+    if (!h || !data) return YH_EINVAL;
+    const TflTensor& t = h->m.tensors[h->m.inputs[0]];
+    if (nbytes != t.count() * t.elem()) return h->fail(YH_EINVAL, "input size mismatch");   // the reference only warns (yolact.rs:151-158)
+    TCHK(h, hipSetDevice(h->dev));
+    TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], data, nbytes, hipMemcpyHostToDevice, h->stream));
+    return YH_OK;
+}
+int yh_tfl_invoke(yh_tfl* h) {
+    if (!h) return YH_EINVAL;
+    TCHK(h, hipSetDevice(h->dev));
+    return run_plan(h);
+}
+int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes) {
+    if (!h || !dst || tensor < 0 || tensor >= (int)h->m.tensors.size()) return YH_EINVAL;
+    const TflTensor& t = h->m.tensors[tensor];
+    if (nbytes != t.count() * t.elem()) return h->fail(YH_EINVAL, "tensor size mismatch");
+    TCHK(h, hipSetDevice(h->dev));
+    TCHK(h, hipMemcpyAsync(dst, h->tens[tensor], nbytes, hipMemcpyDeviceToHost, h->stream));
+    TCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+int yh_tfl_output_read(yh_tfl* h, int32_t i, void* dst, size_t nbytes) {
+    if (!h || i < 0 || i >= (int)h->m.outputs.size()) return YH_EINVAL;
+    return yh_tfl_tensor_read(h, h->m.outputs[i], dst, nbytes);
+}
+
+int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame, int32_t w, int32_t hh, int32_t mode) {
+    if (!h || !frame || w < 1 || hh < 1) return YH_EINVAL;
+    if (mode != YH_COMPAT_STRICT && mode != YH_COMPAT_SANE) return h->fail(YH_EINVAL, "bad compat mode");
+    const TflTensor& in = h->m.tensors[h->m.inputs[0]];
+    if (in.type != TFL_U8 || in.shape.size() != 4 || in.shape[0] != 1 || in.shape[1] != in.shape[2] || in.shape[3] != 3 || in.shape[1] % 8 != 0 || in.shape[1] / 8 > 64)
+        return h->fail(YH_EINVAL, "classify needs a [1,S,S,3] uint8 input with S % 8 == 0");
+    if (h->m.outputs.size() < 5) return h->fail(YH_EINVAL, "classify reads output index 4 (yolact.rs:91): the model has fewer outputs");
+    const TflTensor& o4 = h->m.tensors[h->m.outputs[4]];
+    const int S = in.shape[1], grid = S / 8;
+    const size_t cells = (size_t)grid * grid;
+    if (o4.count() % cells != 0 || o4.count() / cells < 4 || (o4.type != TFL_U8 && o4.type != TFL_F32))
+        return h->fail(YH_EINVAL, "output 4 must hold (S/8)^2 cells of >= 4 uint8 or float32 logits");
+    const int C = (int)(o4.count() / cells);
+    TCHK(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)w * hh;
+    auto grow = [&](void** p, size_t* cap, size_t bytes) { if (bytes <= *cap) return true; if (*p) hipFree(*p); *p = nullptr; *cap = 0; if (hipMalloc(p, bytes) != hipSuccess) return false; *cap = bytes; return true; };
+    const size_t tmp_need = (size_t)12 * ((size_t)w * S > (size_t)2 * S * hh ? (size_t)w * S : (size_t)2 * S * hh);
+    if (!grow((void**)&h->frame_dev, &h->frame_cap, npx * 4) || !grow((void**)&h->rs_tmp, &h->rs_cap, tmp_need)) return h->fail(YH_ENOMEM, "hipMalloc scratch");
+    if (!h->tiles_dev) {
+        if (hipMalloc((void**)&h->tiles_dev, (size_t)2 * S * S * 3) != hipSuccess || hipMalloc((void**)&h->cells_dev, 2 * cells * C * 4) != hipSuccess ||
+            hipMalloc((void**)&h->codes_dev, 2 * cells * 4) != hipSuccess || hipMalloc((void**)&h->stitch_dev, (size_t)2 * S * S * 4) != hipSuccess ||
+            hipMalloc((void**)&h->diverged_dev, 8) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc scratch");
+    }
+    hipStream_t s = h->stream;
+    // yolact.rs:195-214
+    TCHK(h, hipMemcpyAsync(h->frame_dev, frame, npx * 4, hipMemcpyHostToDevice, s));
+    hipError_t e = launch_resize_v_u32(h->frame_dev, w, hh, h->rs_tmp, S, s);
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->tiles_dev, 2 * S, 1, s);
+    if (e != hipSuccess) return h->fail(YH_EHIP, "classify pre failed");
+    for (int t = 0; t < 2; ++t) {   // yolact.rs:216-217: the two tiles, one invoke each (the model is batch 1)
+        TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], h->tiles_dev + (size_t)t * S * S * 3, (size_t)S * S * 3, hipMemcpyDeviceToDevice, s));
+        int rc = run_plan(h);
+        if (rc) return rc;
+        float* dst = h->cells_dev + (size_t)t * cells * C;   // yolact.rs:169-182: outputs -> f32 (results[4])
+        if (o4.type == TFL_U8) hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk((long long)cells * C)), dim3(256), 0, s, (const uint8_t*)h->tens[h->m.outputs[4]], dst, (long long)(cells * C), o4.scale, o4.zp);
+        else TCHK(h, hipMemcpyAsync(dst, h->tens[h->m.outputs[4]], cells * C * 4, hipMemcpyDeviceToDevice, s));
+    }
+    e = launch_cells_postprocess(h->cells_dev, 2, grid, C, mode, h->codes_dev, h->diverged_dev, s);   // yolact.rs:90-131
+    if (e == hipSuccess) e = launch_upsample_codes(h->codes_dev, 2, grid, h->stitch_dev, 1, s);        // :127-128, :219-220
+    if (e == hipSuccess) e = launch_resize_v_u32(h->stitch_dev, 2 * S, S, h->rs_tmp, hh, s);            // :222-231
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, 2 * S, hh, h->frame_dev, w, 2, s);
+    if (e != hipSuccess) return h->fail(YH_EHIP, "classify post failed");
+    int div[2] = { 0, 0 };
+    TCHK(h, hipMemcpyAsync(div, h->diverged_dev, 8, hipMemcpyDeviceToHost, s));
+    TCHK(h, hipStreamSynchronize(s));
+    if (div[0] || div[1]) return h->fail(YH_EDIVERGE, "reference flood fill (yolact.rs:57-78) does not terminate on this frame");
+    TCHK(h, hipMemcpy(frame, h->frame_dev, npx * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+}  // extern "C"

@@ -70,6 +70,19 @@ SYMBOLS = [
     ("yh_profile_run", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_time_steps", _i, [_vp, _i, _i, C.POINTER(_f)]),
     ("yh_flops_per_frame", C.c_double, [_vp]),
+    ("yh_tfl_validate", _i, [_vp, _sz, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    ("yh_tfl_create", _i, [_vp, _sz, _i, C.POINTER(_vp)]),
+    ("yh_tfl_destroy", None, [_vp]),
+    ("yh_tfl_last_error", C.c_char_p, [_vp]),
+    ("yh_tfl_input_info", _i, [_vp, C.POINTER(TensorInfo)]),
+    ("yh_tfl_output_count", _i, [_vp]),
+    ("yh_tfl_output_info", _i, [_vp, _i, C.POINTER(TensorInfo)]),
+    ("yh_tfl_set_input", _i, [_vp, _vp, _sz]),
+    ("yh_tfl_invoke", _i, [_vp]),
+    ("yh_tfl_output_read", _i, [_vp, _i, _vp, _sz]),
+    ("yh_tfl_tensor_count", _i, [_vp]),
+    ("yh_tfl_tensor_read", _i, [_vp, _i, _vp, _sz]),
+    ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -297,3 +310,78 @@ class Engine:
         lb, cb, mb, pb = _f16_bits(loc), _f16_bits(conf), _f16_bits(mask), _f16_bits(proto)
         self._chk(self.L.yh_op_detect(self.h, _p(lb), _p(cb), _p(mb), _p(pb), n))
         self.n = n
+
+
+def tfl_validate(model_bytes):
+    """Parse-only check of a .tflite buffer (no GPU): returns (ok, n_tensors, n_ops, message)."""
+    L = load_library()
+    nt, no = C.c_int32(), C.c_int32()
+    err = C.create_string_buffer(512)
+    rc = L.yh_tfl_validate(model_bytes, len(model_bytes), C.byref(nt), C.byref(no), err, 512)
+    return rc == OK, nt.value, no.value, err.value.decode()
+
+
+_KIND_NP = {1: np.float32, 3: np.uint8, 2: np.int32}
+
+
+class TfliteEngine:
+    """RAII wrapper of yh_tfl: the reference's own model family (uint8 MobileNetV2-style .tflite)."""
+
+    def __init__(self, model_bytes, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.yh_tfl_create(model_bytes, len(model_bytes), device, C.byref(h))
+        if rc != OK:
+            raise YhError(rc, self.L.yh_tfl_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.yh_tfl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise YhError(rc, self.L.yh_tfl_last_error(self.h).decode())
+
+    @staticmethod
+    def _info(ti):
+        return dict(name=ti.name.decode(), kind=ti.kind, dims=tuple(ti.dims[:ti.ndims]), scale=ti.scale, zero_point=ti.zero_point)
+
+    def input_info(self):
+        ti = TensorInfo()
+        self._chk(self.L.yh_tfl_input_info(self.h, C.byref(ti)))
+        return self._info(ti)
+
+    def output_count(self):
+        return self.L.yh_tfl_output_count(self.h)
+
+    def output_info(self, i):
+        ti = TensorInfo()
+        self._chk(self.L.yh_tfl_output_info(self.h, i, C.byref(ti)))
+        return self._info(ti)
+
+    def set_input(self, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.yh_tfl_set_input(self.h, _p(arr), arr.nbytes))
+
+    def invoke(self):
+        self._chk(self.L.yh_tfl_invoke(self.h))
+
+    def output(self, i):
+        info = self.output_info(i)
+        out = np.empty(info["dims"], _KIND_NP[info["kind"]])
+        self._chk(self.L.yh_tfl_output_read(self.h, i, _p(out), out.nbytes))
+        return out
+
+    def tensor(self, index, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._chk(self.L.yh_tfl_tensor_read(self.h, index, _p(out), out.nbytes))
+        return out
+
+    def classify_frame(self, frame_u32, width, height, mode=COMPAT_STRICT):
+        assert frame_u32.dtype == np.uint32 and frame_u32.flags.c_contiguous and frame_u32.size == width * height
+        self._chk(self.L.yh_tfl_classify_frame_u32(self.h, _p(frame_u32), width, height, mode))

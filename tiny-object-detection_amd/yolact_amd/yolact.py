@@ -1,7 +1,9 @@
-"""`Yolact` — mirror of the reference's struct (src/yolact.rs:13-41) over the HIP engine."""
+"""`Yolact` — mirror of the reference's struct (src/yolact.rs:13-41) over the HIP library."""
+import os
+
 import numpy as np
 
-from .capi import COMPAT_STRICT, Engine
+from .capi import COMPAT_STRICT, Engine, TfliteEngine
 
 
 class Yolact:
@@ -12,10 +14,19 @@ class Yolact:
         self.compat_mode = compat_mode
 
     @classmethod
-    def init(cls, weights=None, seed=1, input_size=224, compat_mode=COMPAT_STRICT, device=0, backbone=50):
-        """reference: `Yolact::init()` (src/yolact.rs:17-37). The reference hard-codes its model
-        path and tile size (224, :143-144); the weights file is absent from the checkout, so
-        `weights=None` loads the seeded synthetic blob. Errors raise (the reference `.expect`s)."""
+    def init(cls, model_path=None, weights=None, seed=1, input_size=224, compat_mode=COMPAT_STRICT, device=0, backbone=50):
+        """reference: `Yolact::init()` (src/yolact.rs:17-37), which hard-codes
+        "data/FRC_model_edgetpu.tflite". Here:
+          * model_path = a non-EdgeTPU .tflite (the reference's data/FRC_model.tflite family: uint8
+            MobileNetV2-style graph) -> the TFLite model path runs it on the GPU;
+          * otherwise the YOLACT R50/R101 engine at `input_size` (224 = the reference's tile,
+            yolact.rs:143-144) with `weights` (a YHW1 blob) or the seeded synthetic blob.
+        Errors raise (the reference `.expect`s every failure)."""
+        if model_path is not None:
+            if not os.path.exists(model_path):
+                raise FileNotFoundError(f"failed to load model: {model_path}")   # yolact.rs:20
+            with open(model_path, "rb") as f:
+                return cls(TfliteEngine(f.read(), device=device), compat_mode)
         eng = Engine(input_size=input_size, backbone=backbone, max_batch=2, use_graph=True, device=device)
         eng.load_weights(weights if weights is not None else eng.generate_weights(seed))
         return cls(eng, compat_mode)
