@@ -74,6 +74,19 @@ def test_conv_exact_on_integers(eng, oracle):
     assert np.array_equal(y, yo)
 
 
+@pytest.mark.parametrize("cin,cout,k", [(64, 256, 3), (256, 512, 1), (128, 128, 3), (64, 351, 3)])
+def test_conv_exact_on_integers_big_tiles(eng, oracle, cin, cout, k):
+    """Same exactness check on the 8-wave tiles (256x256 with the 16x16x32 MFMA shape and the split
+    epilogue; 128x256 on the 3-stage ring), ragged M and channel tails included."""
+    rng = np.random.default_rng(cin + cout)
+    x = rng.integers(-3, 4, (3, 13, 11, cin)).astype(np.float32)
+    wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    y = eng.op_conv2d(x, wt, b, 1, k // 2, None, 0)
+    yo = oracle.conv2d(x, wt, b, 1, k // 2, None, 0, f16=True)
+    assert np.array_equal(y, yo)
+
+
 @pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))

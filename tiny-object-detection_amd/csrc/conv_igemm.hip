@@ -37,21 +37,34 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 //              per tile) and a raw s_barrier, so one tile stays in flight across every barrier.
 // EPI: the epilogue's f32 staging image covers TM / EPI rows at a time (a 256 x 256 tile's does not
 //      fit in LDS at once).
+template <int MT, class ACC>
+__device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC c) {
+    if constexpr (MT == 32) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 // SPLITK: the grid also splits K into p.k_slices ranges; each workgroup writes its raw f32 partial
 //      tile to p.partial[slice][m][ch] and splitk_reduce_f16 sums the slices in order (fixed order:
 //      bitwise reproducible), adds bias/residual, activates and rounds. For launches whose M gives
 //      only a handful of tiles (batch 1, deep layers: 12 workgroups streaming 4.7 MB of weights).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false>
+// MT:  MFMA tile edge. 32: v_mfma_f32_32x32x16_f16 (K = 16 per instruction, 16 accumulators per
+//      lane); 16: v_mfma_f32_16x16x32_f16 (K = 32, 4 accumulators per lane: lane l holds output
+//      pixel l & 15 and channels 4 (l >> 4) .. + 3). Same FLOPs per cycle; on real data the chip
+//      holds a higher clock on the 16x16x32 shape (guide: DVFS give-back item 7).
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
-    constexpr int TC = WTC / 32, TMT = WTM / 32;   // MFMA tiles per wave
+    constexpr int TC = WTC / MT, TMT = WTM / MT;   // MFMA tiles per wave
+    constexpr int KS = MT == 32 ? 4 : 2;           // MFMA k-slices per 64-deep step
+    constexpr int NACC = MT == 32 ? 16 : 4;        // accumulator registers per MFMA tile
+    typedef float accv __attribute__((ext_vector_type(NACC)));
     constexpr int XL = TM / RSTEP, WL = TCH / RSTEP;  // LDS-DMA instructions per thread per tile
     constexpr int AB_BYTES = (TCH + TM) * 128;
     constexpr int ES = TCH + 4;                    // epilogue row stride in floats
     constexpr int LDS_BYTES = cmax<STAGES * AB_BYTES, (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
-    static_assert((NW == 4 || NW == 8) && WTC % 32 == 0 && WTM % 32 == 0 && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
+    static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
     static_assert(STAGES == 2 || (STAGES == 3 && !SMALLC), "3-stage ring: no ordinary loads may share the loop");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -161,16 +174,19 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 
     const int lane = tid & 63, wid = tid >> 6;
     const int wc = wid / WM, wm = wid % WM;
-    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
+    // fragment lane map: row (channel / pixel) lr of the MFMA tile, 16-byte k-group lh within a k-slice
+    const int l31 = lane & (MT - 1), lh = MT == 32 ? lane >> 5 : lane >> 4, swz = (l31 >> 1) & 7;
     const int a_row = (wc * WTC + l31) * 128, b_row = TCH * 128 + (wm * WTM + l31) * 128;
+    constexpr int TSTR = MT * 128;                 // LDS bytes between consecutive MFMA tiles' rows
+    constexpr int KG = MT == 32 ? 2 : 4;           // 16-byte k-groups per k-slice
 
-    f32x16 acc[TC][TMT];
+    accv acc[TC][TMT];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TMT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < NACC; ++e) acc[i][j][e] = 0.0f;
 
     if (STAGES == 2) {
         // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
@@ -184,22 +200,21 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             const char* base = lds + cur * AB_BYTES;
             if (more) tile_begin();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((2 * kk + lh) ^ swz) << 4;
+            for (int kk = 0; kk < KS; ++kk) {
+                const int co = ((KG * kk + lh) ^ swz) << 4;
                 half8 a[TC], b[TMT];
 #pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base + a_row + i * 4096 + co);
+                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base + a_row + i * TSTR + co);
 #pragma unroll
-                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base + b_row + j * 4096 + co);
+                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base + b_row + j * TSTR + co);
                 if (more) {
 #pragma unroll
-                    for (int d = (kk * NDMA) / 4; d < ((kk + 1) * NDMA) / 4; ++d) tile_part(cur ^ 1, d);
+                    for (int d = (kk * NDMA) / KS; d < ((kk + 1) * NDMA) / KS; ++d) tile_part(cur ^ 1, d);
                 }
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int j = 0; j < TMT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TMT; ++j) acc[i][j] = mfma_f16<MT>(a[i], b[j], acc[i][j]);
             }
             if (more) tile_end();
             __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
@@ -212,27 +227,26 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         // so the MFMAs of a step never wait on LDS latency (their operands were read one step
         // earlier) and every DMA has two steps to land. Stage k is free for refill after the
         // barrier because every wave drained its reads of tile k (lgkmcnt(0)) before arriving.
-        struct Frag { half8 a[4][TC], b[4][TMT]; };
+        struct Frag { half8 a[KS][TC], b[KS][TMT]; };
         auto read_frags = [&](int buf, Frag& f) {
             const char* base = lds + buf * AB_BYTES;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((2 * kk + lh) ^ swz) << 4;
+            for (int kk = 0; kk < KS; ++kk) {
+                const int co = ((KG * kk + lh) ^ swz) << 4;
 #pragma unroll
-                for (int i = 0; i < TC; ++i) f.a[kk][i] = *(const half8*)(base + a_row + i * 4096 + co);
+                for (int i = 0; i < TC; ++i) f.a[kk][i] = *(const half8*)(base + a_row + i * TSTR + co);
 #pragma unroll
-                for (int j = 0; j < TMT; ++j) f.b[kk][j] = *(const half8*)(base + b_row + j * 4096 + co);
+                for (int j = 0; j < TMT; ++j) f.b[kk][j] = *(const half8*)(base + b_row + j * TSTR + co);
             }
         };
         auto mfma_frags = [&](const Frag& f) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int j = 0; j < TMT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[kk][i], f.b[kk][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TMT; ++j) acc[i][j] = mfma_f16<MT>(f.a[kk][i], f.b[kk][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         };
         const int nk = nk_total;
@@ -311,10 +325,12 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int j = 0; j < TMT; ++j) {
-                    const int m_l = (wm % WMG) * WTM + j * 32 + l31;
+                    const int m_l = (wm % WMG) * WTM + j * MT + l31;
+                    // 32x32: register quad g holds channels 8 g + 4 (lane >> 5) .. + 3; 16x16: the one
+                    // quad holds channels 4 (lane >> 4) .. + 3 (C/D maps of the guide, weights = A operand)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c_l = wc * WTC + i * 32 + 8 * g + 4 * lh;
+                    for (int g = 0; g < NACC / 4; ++g) {
+                        const int c_l = wc * WTC + i * MT + (MT == 32 ? 8 * g + 4 * lh : 4 * lh);
                         f32x4 v = { acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3] };
                         *(f32x4*)(E + m_l * ES + c_l) = v;
                     }
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 
 int conv_tile_ch(ConvTile t) {
     switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x256: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
-                 case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: return 256; }
+                 case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: case TILE_256x256_M16: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
@@ -428,6 +444,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_256x128: return "conv_igemm_f16<256,128,4,2,0,3>";
         case TILE_128x256: return "conv_igemm_f16<128,256,2,4,0,3>";
         case TILE_256x256: return "conv_igemm_f16<256,256,2,4,0,2>";
+        case TILE_256x256_M16: return "conv_igemm_f16<256,256,2,4,0,2,mfma16>";
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
     }
     return "?";
@@ -453,6 +470,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }

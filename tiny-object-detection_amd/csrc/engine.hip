@@ -134,6 +134,7 @@ struct yh_engine {
 
     bool weights_loaded = false;
     int cur_n = 0;
+    int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
 
@@ -231,7 +232,8 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     else p.tile = TILE_128x128;
     p.Kpad = d0.cin == 3 ? round_up(d0.k * ((d0.k + 1) / 2), 8) * 8 : d0.k * d0.k * d0.cin;  // stem: k rows x ceil(k/2) chunks
     // K-heavy layers (>= 8 steps of 64): 8-wave tiles on the 3-stage LDS-DMA ring
-    if (p.tile == TILE_128x128 && p.Kpad >= 512) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    static const int bigk = getenv("YH_BIGK") ? atoi(getenv("YH_BIGK")) : 256;   // A/B switch (tools/)
+    if (p.tile == TILE_128x128 && p.Kpad >= bigk) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
     p.coutPad = round_up(cout, conv_tile_ch(p.tile));
     h->panels.push_back(p);
     return (int)h->panels.size() - 1;
@@ -363,7 +365,26 @@ int build_graph_spec(yh_engine* h) {
     h->ops.push_back(conv_op(h, "p6", add_panel(h, { ci++ }), level(h->pyr, 2), level(h->pyr, 3), 2, 1, 0, nullptr));
     h->ops.push_back(conv_op(h, "p7", add_panel(h, { ci++ }), level(h->pyr, 3), level(h->pyr, 4), 2, 1, 0, nullptr));
     for (int l = 0; l < 5; ++l) { snprintf(nm, sizeof nm, "p%d", l + 3); h->named[nm] = level(h->pyr, l); }
-    // ---- protonet
+    // ---- shared prediction head: trunk, then box|conf|mask fused along cout
+    const int ci_proto = ci;          // proto0..3 + proto out occupy the next five canonical convs
+    ci += 5;
+    const int trunk_panel = add_panel(h, { ci });
+    const int out_panel = add_panel(h, { ci + 1, ci + 2, ci + 3 });
+    ci += 4;
+    const int ci_end = ci;
+    for (int l = 0; l < 5; ++l) {
+        snprintf(nm, sizeof nm, "head_t%d", l);
+        h->ops.push_back(conv_op(h, nm, trunk_panel, level(h->pyr, l), level(h->pyr_t, l), 1, 1, 1, nullptr));
+        h->named[nm] = level(h->pyr_t, l);
+        snprintf(nm, sizeof nm, "head_out%d", l);
+        Op o = conv_op(h, nm, out_panel, level(h->pyr_t, l), level(h->heads, l), 1, 1, 0, nullptr);
+        o.tanh_from = 12 + 3 * h->C;
+        h->ops.push_back(o);
+    }
+    // ---- protonet (listed after the heads so the detection tail's K1-K3, which need only the head
+    // rows, can run on a side stream underneath it; canonical conv indices are unchanged)
+    h->tail_fork_op = (int)h->ops.size();
+    ci = ci_proto;
     Buf q = level(h->pyr, 0);
     for (int i = 0; i < 3; ++i) {
         Buf y;
@@ -379,19 +400,7 @@ int build_graph_spec(yh_engine* h) {
     h->ops.push_back(conv_op(h, "proto3", add_panel(h, { ci++ }), pup, p3b, 1, 1, 1, nullptr));
     if ((rc = new_buf(h, "proto", h->hp, h->wp, 32, &h->proto))) return rc;
     h->ops.push_back(conv_op(h, "proto", add_panel(h, { ci++ }), p3b, h->proto, 1, 0, 1, nullptr));
-    // ---- shared prediction head: trunk, then box|conf|mask fused along cout
-    const int trunk_panel = add_panel(h, { ci });
-    const int out_panel = add_panel(h, { ci + 1, ci + 2, ci + 3 });
-    ci += 4;
-    for (int l = 0; l < 5; ++l) {
-        snprintf(nm, sizeof nm, "head_t%d", l);
-        h->ops.push_back(conv_op(h, nm, trunk_panel, level(h->pyr, l), level(h->pyr_t, l), 1, 1, 1, nullptr));
-        h->named[nm] = level(h->pyr_t, l);
-        snprintf(nm, sizeof nm, "head_out%d", l);
-        Op o = conv_op(h, nm, out_panel, level(h->pyr_t, l), level(h->heads, l), 1, 1, 0, nullptr);
-        o.tanh_from = 12 + 3 * h->C;
-        h->ops.push_back(o);
-    }
+    ci = ci_end;
     if (ci != (int)h->convs.size()) return h->fail(YH_EINVAL, "conv table / graph mismatch");
     // ---- branch concurrency: lanes by role, cross-lane RAW dependencies found by buffer pointer
     // (every tensor is written exactly once per step and never aliased, so RAW is the only hazard)
@@ -486,6 +495,8 @@ ConvTile pick_tile(const Panel& pn, int M) {
         const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
         if (b128 <= 256) return TILE_128x128_S3;
     }
+    static const int mfma16 = getenv("YH_MFMA16") ? atoi(getenv("YH_MFMA16")) : 1;   // A/B switch (tools/): default 16x16x32
+    if (pn.tile == TILE_256x256 && mfma16) return TILE_256x256_M16;
     return pn.tile;
 }
 
@@ -513,6 +524,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     p.act = o.act; p.tanh_from = o.tanh_from;
     // timing-only ablation (tools/): zero-record descriptors drop every load through them
     static const int ablate = getenv("YH_ABLATE") ? atoi(getenv("YH_ABLATE")) : 0;
+
     if (ablate & 1) { p.x_bytes = 0; }
     if (ablate & 2) { p.w_bytes = 0; }
     const ConvTile tile = pick_tile(pn, p.M);
@@ -575,8 +587,23 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     // convs, FPN levels, the shared head per level, the protonet) then run on their own streams,
     // joined by events (also valid under stream capture: the lanes fork from and join the origin).
     const bool multi = n <= 8;
+    bool tail_forked = false;
     if (!multi) {
-        for (const Op& o : h->ops) { int rc = launch_op(h, o, n); if (rc) return rc; }
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            if (with_tail && (int)i == h->tail_fork_op) {
+                // heads are complete: softmax/append, per-class NMS and frame top-k (small, latency-
+                // bound grids) run on lane 1 underneath the protonet's convolutions
+                h->det.n = n;
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->lanes[1], h->ev_fork, 0));
+                for (int st = 0; st < 4; ++st)
+                    if (launch_detect_stage(h->det, st, h->lanes[1]) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
+                HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + 1], h->lanes[1]));
+                tail_forked = true;
+            }
+            int rc = launch_op(h, h->ops[i], n);
+            if (rc) return rc;
+        }
     } else {
         bool used[yh_engine::kLanes] = { true, false, false, false };
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // fork point
@@ -597,7 +624,11 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     }
     if (with_tail) {
         h->det.n = n;
-        hipError_t e = launch_detect(h->det, h->stream);
+        hipError_t e;
+        if (tail_forked) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + 1], 0));
+            e = launch_detect_stage(h->det, 4, h->stream);   // masks: needs the prototypes too
+        } else e = launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
     }
     return YH_OK;
@@ -1180,6 +1211,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
     if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
     const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8
     std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
