@@ -583,10 +583,13 @@ int launch_op_on(yh_engine* h, const Op& o, int n, hipStream_t st) {
 }
 
 int enqueue_all(yh_engine* h, int n, int with_tail) {
-    // Small batches leave most CUs idle inside each launch: independent branches (projection
-    // convs, FPN levels, the shared head per level, the protonet) then run on their own streams,
-    // joined by events (also valid under stream capture: the lanes fork from and join the origin).
-    const bool multi = n <= 8;
+    // Default: one stream, except that the tail's K1-K3 fork onto lane 1 underneath the protonet.
+    // Optional (YH_LANES_MAXN=n): for batches <= n every independent branch (projection convs, FPN
+    // levels, the shared head per level, the protonet) gets its own lane, joined by events (valid
+    // under stream capture). That paid at batch 1 before split-K existed (1.8 -> 1.5 ms); with
+    // split-K filling the GPU per launch it measures 0-6 % slower at every batch size, so it is off.
+    static const int lanes_maxn = getenv("YH_LANES_MAXN") ? atoi(getenv("YH_LANES_MAXN")) : 0;   // A/B switch (tools/)
+    const bool multi = n <= lanes_maxn;
     bool tail_forked = false;
     if (!multi) {
         for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -616,18 +619,29 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
             if (rc) return rc;
             if (o.signal) HIPCHK(h, hipEventRecord(h->op_done[i], st));
         }
+        // every lane's work so far is marked by one event per lane
         for (int l = 1; l < yh_engine::kLanes; ++l)
-            if (used[l]) {  // join
-                HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + l], h->lanes[l]));
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + l], 0));
-            }
+            if (used[l]) HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + l], h->lanes[l]));
+        if (with_tail && used[1]) {
+            // K1-K3 need only the head rows (lanes 1-3): run them on lane 1 while lane 0 still works
+            // through the protonet; the mask kernel joins both
+            for (int l = 2; l < yh_engine::kLanes; ++l)
+                if (used[l]) HIPCHK(h, hipStreamWaitEvent(h->lanes[1], h->op_done[h->ops.size() + l], 0));
+            h->det.n = n;
+            for (int st = 0; st < 4; ++st)
+                if (launch_detect_stage(h->det, st, h->lanes[1]) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
+            HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + 1], h->lanes[1]));
+            tail_forked = true;
+        }
+        for (int l = 1; l < yh_engine::kLanes; ++l)
+            if (used[l]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + l], 0));   // join
     }
     if (with_tail) {
         h->det.n = n;
         hipError_t e;
         if (tail_forked) {
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + 1], 0));
-            e = launch_detect_stage(h->det, 4, h->stream);   // masks: needs the prototypes too
+            e = launch_detect_stage(h->det, 4, h->stream);   // masks: need the prototypes too
         } else e = launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
     }
