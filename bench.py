@@ -80,7 +80,7 @@ def roofline_of(prof):
     return r
 
 
-def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=16):
+def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64):
     """The CPU oracle ("port": oracle/orc_net.c + orc_detect.c, the checker, never the product)
     timed on this host's cores on a bounded sample of the same workload: whole 550x550 frames
     (118.3 GFLOP each, forward + tail) until ~budget_s seconds of CPU work have elapsed."""
