@@ -61,7 +61,25 @@ def dominant_kernel(prof):
     return sym, by
 
 
-def roofline_of(prof):
+def measured_traffic(sym, batch):
+    """HBM-side bytes per launch of `sym` from the committed PMC passes (profiles/*_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied by
+    tools/make_traffic.py). PMC cannot be collected from inside this process; None if the file has
+    no entry for this kernel at this batch size."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        k = t.get("kernels", {}).get(sym)
+        if k and t.get("batch") == batch:
+            return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_of(prof, batch=None):
     sym, by = dominant_kernel(prof)
     d = by[sym]
     total_ms = sum(p["ms"] for p in prof)
@@ -77,6 +95,11 @@ def roofline_of(prof):
              share_of_step=round(d["ms"] / total_ms, 3), algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
              algorithmic_gbytes_hbm=round(d["bytes"] / 1e9, 4),
              hbm_gbs_algorithmic=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1))
+    traffic, src = measured_traffic(sym, batch)
+    if traffic is not None:
+        r["traffic"] = traffic
+        r["traffic_unit"] = "HBM-side bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, KiB->B), vs algorithmic %d" % round(d["bytes"] / d["launches"])
+        r["traffic_source"] = src
     return r
 
 
@@ -183,7 +206,7 @@ def main():
         if rank == 0:
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
-                                   net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1))
+                                   net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -200,7 +223,7 @@ def main():
                    "weights": f"seeded synthetic (seed {a.seed}), BN folded", "detections_first_frames": ndet},
         "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
         "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),
-        "roofline": roofline_of(prof),
+        "roofline": roofline_of(prof, a.batch),
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:
