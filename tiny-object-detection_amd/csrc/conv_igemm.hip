@@ -188,6 +188,34 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #pragma unroll
             for (int e = 0; e < NACC; ++e) acc[i][j][e] = 0.0f;
 
+    // ---- epilogue geometry is known up front; for single-round epilogues the residual rows are
+    // requested NOW, so their HBM latency hides under the whole main loop (the residual 1x1 convs
+    // have 1-4 k-steps: requested after the loop, that latency was fully exposed).
+    constexpr int TPR = TCH / 8, RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
+    const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
+    const int ch = ch_tile * TCH + ch_l;
+    const bool ch_ok = ch < p.cout8;
+    auto offsets = [&](int m, long long& yo, long long& ro) {
+        if (p.y_dense) {
+            yo = (long long)m * p.ldy + ch;
+            ro = (long long)m * p.ldres + ch;
+        } else {
+            const int n = m / PQ, rem = m - n * PQ;
+            yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
+            ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
+        }
+    };
+    half8 rv0[EPI == 1 ? NPASS : 1];
+    if (EPI == 1 && !SPLITK && p.res && ch_ok) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int m = m_tile * TM + pass * RPP + rr;
+            long long yo, ro;
+            offsets(m < p.M ? m : 0, yo, ro);
+            rv0[pass] = *(const half8*)(p.res + ro);
+        }
+    }
+
     if (STAGES == 2) {
         // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
         // step k, between that slice's fragment reads and its MFMAs: DMA issue (the expensive
@@ -287,31 +315,20 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 
     // ---- epilogue: accumulators -> LDS f32 [m][ch] (TM / EPI rows per round), then coalesced rows
     float* E = (float*)lds;
-    constexpr int TPR = TCH / 8, RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
-    const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
-    const int ch = ch_tile * TCH + ch_l;
-    const bool ch_ok = ch < p.cout8;
     float bias8[8];
     {
         const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);  // bias is padded to coutPad
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
-    auto offsets = [&](int m, long long& yo, long long& ro) {
-        if (p.y_dense) {
-            yo = (long long)m * p.ldy + ch;
-            ro = (long long)m * p.ldres + ch;
-        } else {
-            const int n = m / PQ, rem = m - n * PQ;
-            yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
-            ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
-        }
-    };
 #pragma unroll
     for (int h = 0; h < EPI; ++h) {
-        // all residual rows of this thread for this round are requested up front (one latency)
+        // multi-round epilogues: the residual rows of this round are requested up front (one latency)
         half8 rv[NPASS];
-        if (!SPLITK && p.res && ch_ok) {
+        if (EPI == 1) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) rv[pass] = rv0[pass];
+        } else if (!SPLITK && p.res && ch_ok) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m = m_tile * TM + h * EROWS + pass * RPP + rr;

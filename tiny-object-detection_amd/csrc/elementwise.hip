@@ -18,12 +18,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void preprocess_rgb8_f16(const uint8_t* __restrict__ rgb, half_t* __restrict__ out,
                                                            int n, int S, int Hp, int Wp) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long npix = (long long)n * S * S;
-    if (i >= npix) return;
-    const int x = (int)(i % S);
-    const long long r = i / S;
-    const int y = (int)(r % S), b = (int)(r / S);
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;   // grid = (ceil(S/256), S, n)
+    if (x >= S) return;
+    const long long i = ((long long)b * S + y) * S + x;
     const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
     half4v o;
 #pragma unroll
@@ -32,16 +29,12 @@ __global__ __launch_bounds__(256) void preprocess_rgb8_f16(const uint8_t* __rest
     *(half4v*)(out + (((long long)b * Hp + y + 3) * Wp + x + 3) * 4) = o;
 }
 
+// grid = (ceil(wo * c8 / 256), ho, n): the only per-lane division is by the compile-unknown c8.
 __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
-                                                        int n, int h, int w, int c8, int ho, int wo) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * ho * wo * c8;
-    if (t >= total) return;
-    const int cg = (int)(t % c8);
-    long long r = t / c8;
-    const int ox = (int)(r % wo); r /= wo;
-    const int oy = (int)(r % ho);
-    const int b = (int)(r / ho);
+                                                        int h, int w, int c8, int ho, int wo) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= wo * c8) return;
+    const int ox = t / c8, cg = t - ox * c8, oy = blockIdx.y, b = blockIdx.z;
     float m[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
@@ -53,7 +46,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict
         for (int dx = 0; dx < 3; ++dx) {
             const int ix = ox * 2 - 1 + dx;
             if ((unsigned)ix >= (unsigned)w) continue;
-            const half8 v = *(const half8*)(x + (((long long)b * h + iy) * w + ix) * c8 * 8 + cg * 8);
+            const half8 v = *(const half8*)(x + ((((long long)b * h + iy) * w + ix) * c8 + cg) * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) m[e] = (float)v[e] > m[e] ? (float)v[e] : m[e];
         }
@@ -61,21 +54,17 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict
     half8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
-    *(half8*)(y + t * 8) = o;
+    *(half8*)(y + ((((long long)b * ho + oy) * wo + ox) * c8 + cg) * 8) = o;
 }
 
 // Bilinear resize, align_corners = false: src = (dst + 0.5) * in/out - 0.5 clamped at 0.
+// grid = (ceil(wo * c8 / 256), ho, n); the row coordinates are wave-uniform.
 __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
-                                                    int n, int h, int w, int c8, int ho, int wo,
+                                                    int h, int w, int c8, int ho, int wo,
                                                     long long x_img_stride, long long y_img_stride) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * ho * wo * c8;
-    if (t >= total) return;
-    const int cg = (int)(t % c8);
-    long long r = t / c8;
-    const int ox = (int)(r % wo); r /= wo;
-    const int oy = (int)(r % ho);
-    const int b = (int)(r / ho);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= wo * c8) return;
+    const int ox = t / c8, cg = t - ox * c8, oy = blockIdx.y, b = blockIdx.z;
     const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
     float fy = ((float)oy + 0.5f) * sy - 0.5f;
     fy = fy < 0.0f ? 0.0f : fy;
@@ -133,16 +122,16 @@ __global__ __launch_bounds__(256) void cells_f32(const half_t* __restrict__ head
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int Hp, int Wp, hipStream_t s) {
-    hipLaunchKernelGGL(preprocess_rgb8_f16, dim3(nblk((long long)n * S * S)), dim3(256), 0, s, rgb, out4, n, S, Hp, Wp);
+    hipLaunchKernelGGL(preprocess_rgb8_f16, dim3(nblk(S), (unsigned)S, (unsigned)n), dim3(256), 0, s, rgb, out4, n, S, Hp, Wp);
     return hipGetLastError();
 }
 hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s) {
-    hipLaunchKernelGGL(maxpool3x3s2_f16, dim3(nblk((long long)n * ho * wo * (c / 8))), dim3(256), 0, s, x, y, n, h, w, c / 8, ho, wo);
+    hipLaunchKernelGGL(maxpool3x3s2_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo);
     return hipGetLastError();
 }
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
                            long long xs, long long ys, hipStream_t s) {
-    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)n * ho * wo * (c / 8))), dim3(256), 0, s, x, y, n, h, w, c / 8, ho, wo, xs, ys);
+    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys);
     return hipGetLastError();
 }
 hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc, float* conf,
