@@ -480,7 +480,15 @@ int alloc_tail(yh_engine* h) {
 // ------------------------------------------------------------------------------------------------
 // The panel fixes the widest channel tile (coutPad); per launch, fall back to the 4-wave
 // 128 x 128 tile (2 workgroups per CU) when the big tile would leave most of the 256 CUs idle.
-ConvTile pick_tile(const Panel& pn, int M) {
+ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
+    // stride-1 k x k (k odd, 'same' padding) layers: the row-patch kernel shares one activation patch
+    // between the k taps of a kernel row (conv_igemm.hip). A/B switch: YH_ROWPATCH=0 disables.
+    static const int rowpatch = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 1;
+    if (rowpatch && stride == 1 && pn.k == 3 && pad == 1 && pn.cin_store % 64 == 0) {
+        if (pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) >= 192) return TILE_ROWPATCH_256;
+        if (rowpatch >= 2 && (pn.tile == TILE_128x256 || pn.tile == TILE_256x256 || pn.tile == TILE_128x128) &&
+            (long long)((M + 255) / 256) * (pn.coutPad / 128) >= 192) return TILE_ROWPATCH_128;
+    }
     if (pn.tile == TILE_256x256 || pn.tile == TILE_128x256) {
         const int tm = conv_tile_m(pn.tile), tch = conv_tile_ch(pn.tile);
         const long long blocks = (long long)((M + tm - 1) / tm) * (pn.coutPad / tch);
@@ -496,6 +504,8 @@ ConvTile pick_tile(const Panel& pn, int M) {
         if (b128 <= 256) return TILE_128x128_S3;
     }
     static const int mfma16 = getenv("YH_MFMA16") ? atoi(getenv("YH_MFMA16")) : 1;   // A/B switch (tools/): default 16x16x32
+    static const int x3 = getenv("YH_X3") ? atoi(getenv("YH_X3")) : 0;   // A/B switch (tools/): X3W2 ring
+    if (pn.tile == TILE_256x256 && x3) return TILE_256x256_X3;
     if (pn.tile == TILE_256x256 && mfma16) return TILE_256x256_M16;
     return pn.tile;
 }
@@ -527,7 +537,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
 
     if (ablate & 1) { p.x_bytes = 0; }
     if (ablate & 2) { p.w_bytes = 0; }
-    const ConvTile tile = pick_tile(pn, p.M);
+    const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad);
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
     if (tile == TILE_128x128_S3 && p.ksteps >= 8) {
@@ -560,7 +570,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             ConvParams p;
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
-            e = launch_conv(p, pick_tile(h->panels[o.panel], p.M), h->stream);
+            e = launch_conv(p, pick_tile(h->panels[o.panel], p.M, o.stride, o.pad), h->stream);
             break;
         }
         case OP_POOL:
@@ -1191,7 +1201,7 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
         ms[i] = (float)(acc[i] / reps);
         const bool isop = i < nops;
         if (isop && h->ops[i].kind == OP_CONV)  // the tile (hence the kernel symbol) is chosen per launch
-            h->prof_labels[i] = std::string(conv_tile_symbol(pick_tile(h->panels[h->ops[i].panel], n * h->ops[i].P * h->ops[i].Q))) + ":" + h->ops[i].name;
+            h->prof_labels[i] = std::string(conv_tile_symbol(pick_tile(h->panels[h->ops[i].panel], n * h->ops[i].P * h->ops[i].Q, h->ops[i].stride, h->ops[i].pad))) + ":" + h->ops[i].name;
         else h->prof_labels[i] = isop ? h->ops[i].label : detect_stage_name(i - nops);
         if (flops) flops[i] = isop ? h->ops[i].flops_per_img * n : 0.0;
         if (bytes) bytes[i] = isop ? h->ops[i].bytes_per_img * n + h->ops[i].bytes_fixed : 0.0;
@@ -1225,7 +1235,15 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
     if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
-    if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
+    if (tile == TILE_256x256 && getenv("YH_X3") && atoi(getenv("YH_X3"))) tile = TILE_256x256_X3;
+    else if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
+    {   // the op test reaches the row-patch kernel the same way the engine does (no grid-size floor here)
+        const int rp = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 1;
+        if (rp && k == 3 && stride == 1 && pad == 1 && cin % 64 == 0) {
+            if (cout % 256 == 0 && Kpad >= 512) tile = TILE_ROWPATCH_256;
+            else if (rp >= 2 && cout >= 128) tile = TILE_ROWPATCH_128;
+        }
+    }
     const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8
     std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
