@@ -103,7 +103,57 @@ def roofline_of(prof, batch=None):
     return r
 
 
-def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def latency_stats(eng, n=200):
+    """Device time of single steps (one hipEvent pair each on the engine's stream, graph replay):
+    median and p99 over n steps (SURVEY.md §8d timing method)."""
+    import numpy as np
+    t = np.array([eng.time_steps(1) for _ in range(n)])
+    return dict(n=n, median_ms=round(float(np.median(t)), 4), p99_ms=round(float(np.percentile(t, 99)), 4),
+                min_ms=round(float(t.min()), 4))
+
+
+def pcie_inclusive(eng, host_frames, steps=5):
+    """Wall-clock frames/s when the boundary is handed HOST buffers (yh_set_input_u8: pageable
+    host -> device copy of the uint8 frames, then the step, then a sync). Never the headline value."""
+    n = host_frames.shape[0]
+    eng.set_input(host_frames); eng.evaluate(); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.set_input(host_frames); eng.evaluate()
+    eng.sync()
+    return round(n * steps / (time.perf_counter() - t0), 2)
+
+
+def accuracy_vs_oracle(eng_out, orc_out):
+    """Engine vs CPU oracle on the same frame and weights (the restated acceptance target of SURVEY.md
+    §8c; NOT parity with CPU tflite): detections matched by (class, prior); mask IoU over matched pairs."""
+    import numpy as np
+    (ed, em), (od, om) = eng_out, orc_out
+    ek = {(d["class_id"], d["prior"]): i for i, d in enumerate(ed)}
+    inter = union = matched = 0
+    for j, d in enumerate(od):
+        i = ek.get((d["class_id"], d["prior"]))
+        if i is None:
+            continue
+        matched += 1
+        a, b = em[i] > 0, om[j] > 0
+        inter += int(np.logical_and(a, b).sum()); union += int(np.logical_or(a, b).sum())
+    return dict(oracle_dets=len(od), engine_dets=len(ed), matched_class_and_prior=matched,
+                mask_iou_matched=round(inter / union, 5) if union else None)
+
+
+def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None):
     """The CPU oracle ("port": oracle/orc_net.c + orc_detect.c, the checker, never the product)
     timed on this host's cores on a bounded sample of the same workload: whole 550x550 frames
     (118.3 GFLOP each, forward + tail) until ~budget_s seconds of CPU work have elapsed."""
@@ -112,15 +162,25 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64):
     cores = min(os.cpu_count() or 1, 16)
     net = O.Net(50, frames_u8.shape[1], 81, seed=seed)
     pri = net.priors()
-    done, t0 = 0, time.perf_counter()
+    done, t0, first = 0, time.perf_counter(), None
     while done < max_frames and (done == 0 or time.perf_counter() - t0 < budget_s):
         loc, conf, mask, proto = net.forward(frames_u8[:1], f16=True, nthreads=cores)
-        O.detect(loc[0], conf[0], mask[0], proto[0], pri)
+        out = O.detect(loc[0], conf[0], mask[0], proto[0], pri)
+        first = first or out
         done += 1
     dt = time.perf_counter() - t0
-    return dict(value=round(done / dt, 4), unit="frames/s", cores=cores, kind="port",
-                sample=f"{done} frame(s) {frames_u8.shape[1]}x{frames_u8.shape[2]}x3, full forward + detection tail, "
-                       f"f16-storage oracle (OpenMP, {cores} threads), {dt:.1f} s of CPU work")
+    # the reference pins its interpreter to 4 threads (src/yolact.rs:34): one frame at 4 threads beside it
+    t4 = time.perf_counter()
+    loc, conf, mask, proto = net.forward(frames_u8[:1], f16=True, nthreads=min(4, cores))
+    O.detect(loc[0], conf[0], mask[0], proto[0], pri)
+    t4 = time.perf_counter() - t4
+    r = dict(value=round(done / dt, 4), unit="frames/s", cores=cores, kind="port",
+             sample=f"{done} frame(s) {frames_u8.shape[1]}x{frames_u8.shape[2]}x3, full forward + detection tail, "
+                    f"f16-storage oracle (OpenMP, {cores} threads), {dt:.1f} s of CPU work",
+             cpu_model=cpu_model(), host_cores=os.cpu_count(), value_4_threads=round(1.0 / t4, 4))
+    if eng_out is not None:
+        r["engine_vs_oracle_same_frame"] = accuracy_vs_oracle(eng_out, first)
+    return r
 
 
 def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50):
@@ -153,9 +213,18 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
     prof = eng.profile(with_tail=True, reps=3) if rank == 0 else None
     ndet = sum(len(eng.detections(f, want_masks=False)[0]) for f in range(min(batch, 4))) if rank == 0 else 0
     flops = eng.flops_per_frame()
-    host_frame = bufs[0][:1].cpu().numpy() if rank == 0 else None
+    aux = {}
+    if rank == 0:
+        host = bufs[0].cpu().numpy()
+        aux["host_frame"] = host[:1]
+        aux["latency"] = latency_stats(eng)
+        aux["pcie_inclusive_fps"] = pcie_inclusive(eng, host)
+        eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
+        aux["dets_frame0"] = eng.detections(0, want_masks=True)
+    if dist is not None:
+        dist.barrier()
     eng.close()
-    return dt, prof, flops, ndet, host_frame
+    return dt, prof, flops, ndet, aux
 
 
 def main():
@@ -196,17 +265,18 @@ def main():
     broadcast_weights(dist, blob)
     torch.cuda.synchronize()
 
-    dt, prof, flops, ndet, frame = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
+    dt, prof, flops, ndet, aux = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
                                               a.seed, a.size, blob.data_ptr(), nbytes, backbone=a.backbone)
     extra = {}
     if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
         s1 = max(a.steps * 4, 40)
-        dt1, prof1, _, _, _ = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
+        dt1, prof1, _, _, aux1 = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
                                          blob.data_ptr(), nbytes, backbone=a.backbone)
         if rank == 0:
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
-                                   net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1))
+                                   net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
+                                   latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"])
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -224,10 +294,12 @@ def main():
         "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
         "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),
         "roofline": roofline_of(prof, a.batch),
+        "latency": aux["latency"],
+        "pcie_inclusive_fps": aux["pcie_inclusive_fps"],
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(a.seed, frame)
+        line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], eng_out=aux["dets_frame0"])
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         kt0 = kslice * p.ksteps_per_slice;
         nk_total = p.ksteps - kt0 < p.ksteps_per_slice ? p.ksteps - kt0 : p.ksteps_per_slice;
     }
-    const int ch_tile = tile_id % p.n_ch_tiles, m_tile = tile_id / p.n_ch_tiles;
+    const int ch_tile = tile_id % p.n_ch_tiles, m_tile = tile_id / p.n_ch_tiles + p.m_tile0;
 
     const int tid = threadIdx.x, chunk = tid & 7, rb = tid >> 3;
     const int PQ = p.P * p.Q;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 // Tile: TCH x 256 pixels, 8 waves (2 x 4), v_mfma_f32_16x16x32_f16, weights double-buffered, patches
 // double-buffered (320 rows each: 5 DMA pieces per wave, so one counted vmcnt fits every wave).
 // ------------------------------------------------------------------------------------------------
-template <int TCH, int EPI>
+template <int TCH, int EPI, int S>
 __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) {
     constexpr int TM = 256, WCH = 2, WM = 4, NT = 512, MT = 16, KS = 2, KG = 4;
     constexpr int WTC = TCH / WCH, WTM = TM / WM, TC = WTC / MT, TMT = WTM / MT;
@@ -504,11 +504,11 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ch_tile = wg % p.n_ch_tiles, m_tile = wg / p.n_ch_tiles;
+    const int ch_tile = wg % p.n_ch_tiles, m_tile = wg / p.n_ch_tiles + p.m_tile0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W, m0 = m_tile * TM, NHW = p.N * HW;
-    const int R = p.R, S = p.S, pad = p.pad;
+    const int R = p.R, pad = p.pad;   // S (kernel width) is a template constant: the S steps of a patch are unrolled
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -520,7 +520,6 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
     const unsigned wbase = (unsigned)(((ch_tile * TCH + rbw) * p.ldw + lcw * 8) * 2);
     // ---- patch staging: piece (rd * 8 + wave) = 8 patch rows; thread -> patch row j, physical chunk lane & 7
     int pj[NXP];           // patch row of this thread in round rd
-    unsigned pvo[NXP];     // byte offset of that row's pixel at r == pad, chunk 0 (or invalid marker)
 #pragma unroll
     for (int rd = 0; rd < NXP; ++rd) pj[rd] = (rd * 8 + wave) * 8 + (lane >> 3);
 
@@ -528,6 +527,15 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
     const int wid = tid >> 6, wc = wid / WM, wm = wid % WM;
     const int l15 = lane & 15, lh = lane >> 4;
     const int a_row = (wc * WTC + l15) * 128, a_swz = (l15 >> 1) & 7;
+    // B fragment byte offsets inside a patch for tap s (row + s, swizzle of that row), k-slice 0; k-slice 1 is ^ 64
+    int b_off[S][TMT];
+#pragma unroll
+    for (int sx = 0; sx < S; ++sx)
+#pragma unroll
+        for (int j = 0; j < TMT; ++j) {
+            const int row = wm * WTM + j * MT + l15 + sx;
+            b_off[sx][j] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+        }
     // validity bits of this lane's TMT output pixels: bit (r * S + s)
     unsigned vbits[TMT];
 #pragma unroll
@@ -583,6 +591,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
         int r2 = r + 1, kc2 = kc;
         if (r2 == R) { r2 = 0; kc2 += 64; }
         const bool more_patch = pt + 1 < npatches;
+#pragma unroll
         for (int sx = 0; sx < S; ++sx) {
             const bool last_step = !more_patch && sx == S - 1;
             // K position of the NEXT step's weights
@@ -601,10 +610,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
 #pragma unroll
                 for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base_w + a_row + i * (MT * 128) + aco);
 #pragma unroll
-                for (int j = 0; j < TMT; ++j) {
-                    const int row = wm * WTM + j * MT + l15 + sx;
-                    b[j] = *(const half8*)(base_x + row * 128 + (((KG * kk + lh) ^ ((row >> 1) & 7)) << 4));
-                }
+                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base_x + (b_off[sx][j] ^ (kk << 6)));
                 if (wave_mask) {
 #pragma unroll
                     for (int j = 0; j < TMT; ++j)
@@ -766,12 +772,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x256: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
                  case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_X3: case TILE_ROWPATCH_256: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_256x128: return 128; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -784,6 +790,8 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_256x256: return "conv_igemm_f16<256,256,2,4,0,2>";
         case TILE_256x256_M16: return "conv_igemm_f16<256,256,2,4,0,2,mfma16>";
         case TILE_256x256_X3: return "conv_igemm_f16<256,256,2,4,0,x3w2,mfma16>";
+        case TILE_128x128_M16: return "conv_igemm_f16<128,128,2,2,0,2,mfma16>";
+        case TILE_128x128_S3_M16: return "conv_igemm_f16<128,128,2,2,0,3,mfma16>";
         case TILE_ROWPATCH_256: return "conv_rowpatch_f16<256,2>";
         case TILE_ROWPATCH_128: return "conv_rowpatch_f16<128,1>";
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
@@ -793,7 +801,8 @@ const char* conv_tile_symbol(ConvTile t) {
 
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const int tm = conv_tile_m(tile);
-    const int n_m_tiles = (p.M + tm - 1) / tm;
+    const int n_m_tiles = (p.M + tm - 1) / tm - p.m_tile0;
+    if (n_m_tiles < 1) return hipErrorInvalidValue;
     if (p.k_slices > 1) {
         if (tile != TILE_128x128_S3) return hipErrorInvalidValue;
         hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), dim3((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices)),
@@ -811,8 +820,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
-        case TILE_ROWPATCH_256: hipLaunchKernelGGL((conv_rowpatch_f16<256, 2>), grid, dim3(512), 0, stream, p); break;
-        case TILE_ROWPATCH_128: hipLaunchKernelGGL((conv_rowpatch_f16<128, 1>), grid, dim3(512), 0, stream, p); break;
+        case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
+        case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
+        case TILE_ROWPATCH_256: hipLaunchKernelGGL((conv_rowpatch_f16<256, 2, 3>), grid, dim3(512), 0, stream, p); break;
+        case TILE_ROWPATCH_128: hipLaunchKernelGGL((conv_rowpatch_f16<128, 1, 3>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256_X3: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 5, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;

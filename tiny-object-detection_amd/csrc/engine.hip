@@ -480,10 +480,19 @@ int alloc_tail(yh_engine* h) {
 // ------------------------------------------------------------------------------------------------
 // The panel fixes the widest channel tile (coutPad); per launch, fall back to the 4-wave
 // 128 x 128 tile (2 workgroups per CU) when the big tile would leave most of the 256 CUs idle.
+ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad);
 ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
+    // A/B switch (tools/): the 16x16x32 forms of the 128 x 128 tiles everywhere
+    static const int small16 = getenv("YH_SMALL16") ? atoi(getenv("YH_SMALL16")) : 0;
+    const ConvTile t = pick_tile_base(pn, M, stride, pad);
+    if (small16 && t == TILE_128x128) return TILE_128x128_M16;
+    if (small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
+    return t;
+}
+ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad) {
     // stride-1 k x k (k odd, 'same' padding) layers: the row-patch kernel shares one activation patch
     // between the k taps of a kernel row (conv_igemm.hip). A/B switch: YH_ROWPATCH=0 disables.
-    static const int rowpatch = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 1;
+    static const int rowpatch = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;   // measured slower: off
     if (rowpatch && stride == 1 && pn.k == 3 && pad == 1 && pn.cin_store % 64 == 0) {
         if (pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) >= 192) return TILE_ROWPATCH_256;
         if (rowpatch >= 2 && (pn.tile == TILE_128x256 || pn.tile == TILE_256x256 || pn.tile == TILE_128x128) &&
@@ -508,6 +517,25 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
     if (pn.tile == TILE_256x256 && x3) return TILE_256x256_X3;
     if (pn.tile == TILE_256x256 && mfma16) return TILE_256x256_M16;
     return pn.tile;
+}
+
+// Wave quantisation: the 8-wave tiles run one workgroup per CU, so a grid of r * 256 + t workgroups
+// takes r + 1 rounds however small t is (35 x 35 levels at batch 64: 307 workgroups = 2 rounds for
+// 1.2 rounds of work). When the last round would be less than half full, the launch is split:
+// the first r * 256 workgroups' rows on the big tile, the remaining rows on 128 x 128 tiles (two
+// workgroups per CU, a quarter of the work each), which fill the chip again. Returns the number of
+// big row tiles in phase one, 0 = single launch. A/B switch: YH_TAILSPLIT=0.
+int tail_split_tiles(const Panel& pn, const ConvParams& p, ConvTile tile) {
+    static const int on = getenv("YH_TAILSPLIT") ? atoi(getenv("YH_TAILSPLIT")) : 1;
+    if (!on || p.k_slices > 1 || pn.coutPad % 128 != 0) return 0;
+    if (tile != TILE_256x256_M16) return 0;   // the only big tile whose bits the small 16x16x32 tiles reproduce
+    const int tm = conv_tile_m(tile), nch = pn.coutPad / conv_tile_ch(tile);
+    const int m_tiles = (p.M + tm - 1) / tm;
+    const long long blocks = (long long)m_tiles * nch;
+    const int r = (int)(blocks / 256), t = (int)(blocks % 256);
+    if (r < 1 || r > 8 || t == 0 || t > 128) return 0;
+    const int mt1 = (r * 256) / nch;
+    return mt1 >= 1 && mt1 < m_tiles ? mt1 : 0;
 }
 
 int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
@@ -570,7 +598,22 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             ConvParams p;
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
-            e = launch_conv(p, pick_tile(h->panels[o.panel], p.M, o.stride, o.pad), h->stream);
+            const Panel& pn = h->panels[o.panel];
+            const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad);
+            const int mt1 = tail_split_tiles(pn, p, tile);
+            if (mt1 == 0) { e = launch_conv(p, tile, h->stream); break; }
+            // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles
+            ConvParams a = p, b = p;
+            a.M = mt1 * conv_tile_m(tile);
+            e = launch_conv(a, tile, h->stream);
+            if (e != hipSuccess) break;
+            b.m_tile0 = a.M / 128;
+            b.n_ch_tiles = pn.coutPad / 128;
+            const long long tb = (long long)((p.M - a.M + 127) / 128) * b.n_ch_tiles;
+            // the 16x16x32 forms of the small tile accumulate every output element in the same order as the
+            // big tile does, so a row's bits do not depend on which phase computed it
+            const bool m16 = tile == TILE_256x256_M16;
+            e = launch_conv(b, tb <= 256 ? (m16 ? TILE_128x128_S3_M16 : TILE_128x128_S3) : (m16 ? TILE_128x128_M16 : TILE_128x128), h->stream);
             break;
         }
         case OP_POOL:
@@ -1238,7 +1281,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     if (tile == TILE_256x256 && getenv("YH_X3") && atoi(getenv("YH_X3"))) tile = TILE_256x256_X3;
     else if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
     {   // the op test reaches the row-patch kernel the same way the engine does (no grid-size floor here)
-        const int rp = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 1;
+        const int rp = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;
         if (rp && k == 3 && stride == 1 && pad == 1 && cin % 64 == 0) {
             if (cout % 256 == 0 && Kpad >= 512) tile = TILE_ROWPATCH_256;
             else if (rp >= 2 && cout >= 128) tile = TILE_ROWPATCH_128;

@@ -32,7 +32,8 @@ struct ConvParams {
     int N, H, W, C;       // input
     int P, Q;             // output spatial
     int R, S, stride, pad;
-    int M;                // N*P*Q
+    int M;                // N*P*Q (rows this launch may write: m < M)
+    int m_tile0;          // first row tile of this launch (two-phase launches: the tail starts past 0)
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
@@ -47,7 +48,8 @@ struct ConvParams {
     float* partial;       // [k_slices][M][partial_ld] f32 workspace
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8, TILE_256x256_X3 = 9, TILE_ROWPATCH_256 = 10, TILE_ROWPATCH_128 = 11 };
+enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8, TILE_256x256_X3 = 9, TILE_ROWPATCH_256 = 10, TILE_ROWPATCH_128 = 11,
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13 };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
