@@ -18,6 +18,7 @@
 //                         registers, coefficients of all detections sit in LDS; mask bit =
 //                         (fma chain > 0) && inside crop window   [sigmoid(x) > 0.5 <=> x > 0].
 #include "yh_internal.h"
+#include <cstdlib>
 
 namespace yh {
 
@@ -61,6 +62,60 @@ __global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int c = 1; c < C; ++c) {
         const float pc = valid ? __fdiv_rn(z[c], s) : 0.0f;
+        const bool hit = pc > p.conf_thresh;
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;  // wave-uniform
+        const int list = b * (C - 1) + (c - 1);
+        int base = 0;
+        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&p.cls_count[list], __popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1);
+        if (hit) p.cand[(long long)list * p.P + base + __popcll(mask & lt)] = make_uint2(__float_as_uint(pc), (unsigned)pr);
+    }
+}
+
+// K1 for a compile-time class count (the 81-class configuration): logits staged as f16 (what the
+// heads hold anyway: 2 C bytes per lane instead of 4 C, so 15 instead of 6 waves fit a CU) and the
+// C exponentials kept in registers between the sum and the threshold pass. Same arithmetic, same
+// order, same candidates as the generic kernel above.
+template <int C>
+__global__ __launch_bounds__(192) void det_softmax_cand_c(const DetectParams p) {
+    __shared__ __attribute__((aligned(16))) half_t zh[192 * C];  // [192][C]
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int c0 = blockIdx.x * YH_K1_ROWS;
+    const half_t* rows = p.heads + ((long long)b * p.cells + c0) * p.ldh;
+    const int nrows = p.cells - c0 < YH_K1_ROWS ? p.cells - c0 : YH_K1_ROWS;
+    const int chunks = p.ldh / 8;
+    for (int i = tid; i < nrows * chunks; i += 192) {
+        const int rl = i / chunks, j = i - rl * chunks;
+        const half8 v = *(const half8*)(rows + (long long)rl * p.ldh + j * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = j * 8 + e - 12;
+            if (q >= 0 && q < 3 * C) zh[rl * 3 * C + q] = v[e];
+        }
+    }
+    __syncthreads();
+    const bool valid = tid / 3 < nrows;
+    const int pr = (c0 + tid / 3) * 3 + tid % 3;
+    const half_t* z = zh + tid * C;
+    float e[C];
+    float s = 1.0f;
+    if (valid) {
+        float m = (float)z[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) { const float v = (float)z[c]; m = v > m ? v : m; }
+        s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { e[c] = spec_expf(__fsub_rn((float)z[c], m)); s = __fadd_rn(s, e[c]); }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) e[c] = 0.0f;
+    }
+    const int lane = tid & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+        const float pc = valid ? __fdiv_rn(e[c], s) : 0.0f;
         const bool hit = pc > p.conf_thresh;
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;  // wave-uniform
@@ -312,8 +367,10 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
     switch (stage) {
         case 0: return hipMemsetAsync(p.cls_count, 0, sizeof(int) * (size_t)p.n * (p.C - 1), s);
         case 1: {
-            hipLaunchKernelGGL(det_softmax_cand, dim3((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n), dim3(192),
-                               (size_t)192 * p.C * sizeof(float), s, p);
+            const dim3 grid((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n);
+            static const bool generic = getenv("YH_K1_GENERIC") && atoi(getenv("YH_K1_GENERIC"));   // A/B switch (tools/)
+            if (p.C == 81 && !generic) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
+            else hipLaunchKernelGGL(det_softmax_cand, grid, dim3(192), (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }
         case 2: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
