@@ -150,6 +150,33 @@ def test_tail_on_crafted_inputs(built, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("C", [81, 21])
+def test_tail_random_logits_both_class_counts(built, oracle, C):
+    """yh_op_detect on random heads for the 81-class kernel (f16 staging, exponentials in registers)
+    and for another class count (generic kernel, exponentials parked in LDS): both must equal the
+    oracle bit for bit, ragged last workgroup included (cells % 64 != 0 at this size)."""
+    import yolact_amd as ya
+    eng = ya.Engine(input_size=96, max_batch=2, use_graph=False, num_classes=C)
+    P, hp = eng.P, eng.hp
+    pri = eng.priors()
+    rng = np.random.default_rng(C)
+    h = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    loc = h(rng.normal(0, 0.4, (2, P, 4)))
+    conf = rng.normal(0, 2.0, (2, P, C))
+    conf[:, :, 0] += 3.0
+    conf = h(conf)
+    mask = h(np.tanh(rng.normal(0, 1, (2, P, 32))))
+    proto = h(np.maximum(rng.normal(0, 1, (2, hp, hp, 32)), 0))
+    eng.op_detect(loc, conf, mask, proto)
+    for f in range(2):
+        d, m = eng.detections(f)
+        od, om = oracle.detect(loc[f], conf[f], mask[f], proto[f], pri, num_classes=C)
+        assert len(od) > 10
+        assert [(x["class_id"], x["prior"], x["score"], x["box"]) for x in d] == [(x["class_id"], x["prior"], x["score"], x["box"]) for x in od]
+        assert np.array_equal(m, om)
+    eng.close()
+
+
 def test_batch_of_two_equals_two_singles(setup, golden_dir):
     eng, _, _ = setup
     img = _frames(golden_dir)

@@ -115,6 +115,49 @@ def test_conv_rowpatch_exact_on_integers(eng, oracle, mode, n, h, w, cin, cout, 
     assert np.array_equal(y, yo)
 
 
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [
+    (64, 256, 3, 5, 17, 16),     # 6 row tiles on "4 CUs": one whole round on the big tile + a tail on 128x128 tiles
+    (128, 512, 1, 5, 17, 16),    # two channel tiles: the phase boundary falls between row tiles
+    (64, 351, 3, 5, 17, 16),     # 384 padded channels: 256-wide launch + 128-wide launch
+    (64, 351, 1, 3, 21, 19),
+])
+def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n, h, w):
+    """Two-phase (wave-quantisation tail) and channel-split launch plans, reached with small
+    tensors by planning for a 4-CU chip (YH_PLAN_CUS): same bits as the oracle, and the same
+    bits as the single-launch plan."""
+    import os
+    rng = np.random.default_rng(cin + cout + k)
+    x = f16(rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32))
+    wt = f16(rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32))
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    r = f16(rng.integers(-5, 6, (n, h, w, cout)).astype(np.float32))
+    single = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
+    os.environ["YH_PLAN_CUS"] = "4"
+    try:
+        split = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
+    finally:
+        os.environ.pop("YH_PLAN_CUS")
+    yo = oracle.conv2d(x, wt, b, 1, k // 2, r, 1, f16=True)
+    assert np.array_equal(split, yo) and np.array_equal(single, yo)
+
+
+def test_conv_two_phase_plan_is_bitwise_identical_on_random_data(eng):
+    """Random (non-exact) data: the tail phase's 128x128 16x16x32 tiles must accumulate each output
+    element in the same order as the 256x256 tile, so the plan cannot change a single bit."""
+    import os
+    rng = np.random.default_rng(77)
+    x = f16(rng.normal(0, 1, (5, 17, 16, 128)))
+    wt = f16(rng.normal(0, 1, (256, 3, 3, 128)) / 34)
+    b = rng.normal(0, 0.1, 256).astype(np.float32)
+    single = eng.op_conv2d(x, wt, b, 1, 1, None, 1)
+    os.environ["YH_PLAN_CUS"] = "4"
+    try:
+        split = eng.op_conv2d(x, wt, b, 1, 1, None, 1)
+    finally:
+        os.environ.pop("YH_PLAN_CUS")
+    assert np.array_equal(single, split)
+
+
 @pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         kt0 = kslice * p.ksteps_per_slice;
         nk_total = p.ksteps - kt0 < p.ksteps_per_slice ? p.ksteps - kt0 : p.ksteps_per_slice;
     }
-    const int ch_tile = tile_id % p.n_ch_tiles, m_tile = tile_id / p.n_ch_tiles + p.m_tile0;
+    const int ch_tile = tile_id % p.n_ch_tiles + p.ch_tile0, m_tile = tile_id / p.n_ch_tiles + p.m_tile0;
 
     const int tid = threadIdx.x, chunk = tid & 7, rb = tid >> 3;
     const int PQ = p.P * p.Q;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ch_tile = wg % p.n_ch_tiles, m_tile = wg / p.n_ch_tiles + p.m_tile0;
+    const int ch_tile = wg % p.n_ch_tiles + p.ch_tile0, m_tile = wg / p.n_ch_tiles + p.m_tile0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W, m0 = m_tile * TM, NHW = p.N * HW;

@@ -345,12 +345,14 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     }
     uint8_t* mo = p.masks + (long long)b * p.max_dets * npx + px;
     for (int d = 0; d < nd; ++d) {
-        const float* co = coef + d * 32;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc = __fmaf_rn(pv[k], co[k], acc);
         const float4 c = crop[d];
         const bool inside = fx >= c.x && fx < c.y && fy >= c.z && fy < c.w;
+        float acc = 0.0f;
+        if (__ballot(inside) != 0ull) {   // wave-uniform: no lane of these 64 pixels lies in the crop window -> all zeros
+            const float* co = coef + d * 32;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc = __fmaf_rn(pv[k], co[k], acc);
+        }
         mo[(long long)d * npx] = (uint8_t)((inside && acc > 0.0f) ? 1 : 0);
     }
 }

@@ -519,23 +519,62 @@ ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad) {
     return pn.tile;
 }
 
+// Launch planning. The CU count the plan assumes can be overridden (YH_PLAN_CUS) so that the tests
+// reach both split forms with small tensors; the results do not depend on the plan.
+static int plan_cus() {
+    const char* e = getenv("YH_PLAN_CUS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256;
+}
+
 // Wave quantisation: the 8-wave tiles run one workgroup per CU, so a grid of r * 256 + t workgroups
 // takes r + 1 rounds however small t is (35 x 35 levels at batch 64: 307 workgroups = 2 rounds for
 // 1.2 rounds of work). When the last round would be less than half full, the launch is split:
 // the first r * 256 workgroups' rows on the big tile, the remaining rows on 128 x 128 tiles (two
 // workgroups per CU, a quarter of the work each), which fill the chip again. Returns the number of
 // big row tiles in phase one, 0 = single launch. A/B switch: YH_TAILSPLIT=0.
-int tail_split_tiles(const Panel& pn, const ConvParams& p, ConvTile tile) {
+int tail_split_tiles(int coutPad, const ConvParams& p, ConvTile tile) {
     static const int on = getenv("YH_TAILSPLIT") ? atoi(getenv("YH_TAILSPLIT")) : 1;
-    if (!on || p.k_slices > 1 || pn.coutPad % 128 != 0) return 0;
+    if (!on || p.k_slices > 1 || coutPad % 128 != 0 || p.m_tile0 || p.ch_tile0) return 0;
     if (tile != TILE_256x256_M16) return 0;   // the only big tile whose bits the small 16x16x32 tiles reproduce
-    const int tm = conv_tile_m(tile), nch = pn.coutPad / conv_tile_ch(tile);
+    const int cus = plan_cus();
+    const int tm = conv_tile_m(tile), nch = coutPad / conv_tile_ch(tile);
     const int m_tiles = (p.M + tm - 1) / tm;
     const long long blocks = (long long)m_tiles * nch;
-    const int r = (int)(blocks / 256), t = (int)(blocks % 256);
-    if (r < 1 || r > 8 || t == 0 || t > 128) return 0;
-    const int mt1 = (r * 256) / nch;
+    const int r = (int)(blocks / cus), t = (int)(blocks % cus);
+    if (r < 1 || r > 8 || t == 0 || t > cus / 2) return 0;
+    const int mt1 = (r * cus) / nch;
     return mt1 >= 1 && mt1 < m_tiles ? mt1 : 0;
+}
+
+hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream) {
+    // channel split: 384 padded output channels (the shared head's 351) = one 256-wide tile on the
+    // fastest kernel + one 128-wide tile, instead of three 128-wide ones. A/B switch: YH_CHSPLIT=0.
+    static const int chsplit = getenv("YH_CHSPLIT") ? atoi(getenv("YH_CHSPLIT")) : 1;
+    const int mt256 = (p.M + 255) / 256, cus = plan_cus();
+    // (only where the 256-wide launch's last round is reasonably full: it runs one workgroup per CU)
+    const bool rounds_ok = mt256 >= 4 * cus || mt256 % cus == 0 || mt256 % cus > cus / 2;
+    if (chsplit && tile == TILE_128x256 && coutPad == 384 && p.k_slices == 1 && mt256 >= cus * 3 / 4 && rounds_ok) {
+        ConvParams a = p, b = p;
+        a.n_ch_tiles = 1;
+        hipError_t e = launch_conv(a, TILE_256x256_M16, stream);
+        if (e != hipSuccess) return e;
+        b.n_ch_tiles = 1; b.ch_tile0 = 2;
+        return launch_conv(b, TILE_128x256, stream);
+    }
+    const int mt1 = tail_split_tiles(coutPad, p, tile);
+    if (mt1 == 0) return launch_conv(p, tile, stream);
+    // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles whose
+    // 16x16x32 MFMA form accumulates every output element in the same order as the big tile does,
+    // so a row's bits do not depend on which phase computed it
+    ConvParams a = p, b = p;
+    a.M = mt1 * conv_tile_m(tile);
+    hipError_t e = launch_conv(a, tile, stream);
+    if (e != hipSuccess) return e;
+    b.m_tile0 = a.M / 128;
+    b.n_ch_tiles = coutPad / 128;
+    const long long tb = (long long)((p.M - a.M + 127) / 128) * b.n_ch_tiles;
+    return launch_conv(b, tb <= plan_cus() ? TILE_128x128_S3_M16 : TILE_128x128_M16, stream);
 }
 
 int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
@@ -599,21 +638,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
             const Panel& pn = h->panels[o.panel];
-            const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad);
-            const int mt1 = tail_split_tiles(pn, p, tile);
-            if (mt1 == 0) { e = launch_conv(p, tile, h->stream); break; }
-            // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles
-            ConvParams a = p, b = p;
-            a.M = mt1 * conv_tile_m(tile);
-            e = launch_conv(a, tile, h->stream);
-            if (e != hipSuccess) break;
-            b.m_tile0 = a.M / 128;
-            b.n_ch_tiles = pn.coutPad / 128;
-            const long long tb = (long long)((p.M - a.M + 127) / 128) * b.n_ch_tiles;
-            // the 16x16x32 forms of the small tile accumulate every output element in the same order as the
-            // big tile does, so a row's bits do not depend on which phase computed it
-            const bool m16 = tile == TILE_256x256_M16;
-            e = launch_conv(b, tb <= 256 ? (m16 ? TILE_128x128_S3_M16 : TILE_128x128_S3) : (m16 ? TILE_128x128_M16 : TILE_128x128), h->stream);
+            e = launch_conv_planned(p, pick_tile(pn, p.M, o.stride, o.pad), pn.coutPad, h->stream);
             break;
         }
         case OP_POOL:
@@ -1326,7 +1351,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
         p.N = n; p.H = hh; p.W = ww; p.C = cs; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
         p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad; p.ksteps = Kpad / 64; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
         p.act = act == 1 ? 1 : 0; p.tanh_from = act == 2 ? 0 : INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile);
-        e = launch_conv(p, tile, h->stream);
+        e = launch_conv_planned(p, tile, coutPad, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(ys.data(), dy, ys.size() * 2, hipMemcpyDeviceToHost);

@@ -34,6 +34,7 @@ struct ConvParams {
     int R, S, stride, pad;
     int M;                // N*P*Q (rows this launch may write: m < M)
     int m_tile0;          // first row tile of this launch (two-phase launches: the tail starts past 0)
+    int ch_tile0;         // first channel tile of this launch (channel-split launches), in units of this launch's tile
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
