@@ -118,8 +118,8 @@ def test_conv_rowpatch_exact_on_integers(eng, oracle, mode, n, h, w, cin, cout, 
 @pytest.mark.parametrize("cin,cout,k,n,h,w", [
     (64, 256, 3, 5, 17, 16),     # 6 row tiles on "4 CUs": one whole round on the big tile + a tail on 128x128 tiles
     (128, 512, 1, 5, 17, 16),    # two channel tiles: the phase boundary falls between row tiles
-    (64, 351, 3, 5, 17, 16),     # 384 padded channels: 256-wide launch + 128-wide launch
-    (64, 351, 1, 3, 21, 19),
+    (64, 351, 3, 5, 17, 12),     # 384 padded channels, 4 row tiles: 256-wide launch + 128-wide launch
+    (64, 351, 1, 3, 21, 16),
 ])
 def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n, h, w):
     """Two-phase (wave-quantisation tail) and channel-split launch plans, reached with small
