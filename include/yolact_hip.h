@@ -221,6 +221,9 @@ int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, in
  * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
  * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. */
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst_host, size_t nfloats, int32_t dims[4]);
+/* Test hook: number of conv kernel launches the last yh_op_conv2d_f16 on this handle was planned as
+ * (1 = single launch, 2 = two-phase or channel-split plan; the split-K reduce is not counted). */
+int yh_debug_last_conv_launches(const yh_engine* h);
 
 /* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */
 

@@ -117,9 +117,9 @@ def test_conv_rowpatch_exact_on_integers(eng, oracle, mode, n, h, w, cin, cout, 
 
 @pytest.mark.parametrize("cin,cout,k,n,h,w", [
     (64, 256, 3, 5, 17, 16),     # 6 row tiles on "4 CUs": one whole round on the big tile + a tail on 128x128 tiles
-    (128, 512, 1, 5, 17, 16),    # two channel tiles: the phase boundary falls between row tiles
+    (512, 512, 1, 5, 16, 16),    # two channel tiles x 5 row tiles: 2 rounds + a tail of 2 workgroups
     (64, 351, 3, 5, 17, 12),     # 384 padded channels, 4 row tiles: 256-wide launch + 128-wide launch
-    (64, 351, 1, 3, 21, 16),
+    (512, 351, 1, 3, 21, 16),
 ])
 def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n, h, w):
     """Two-phase (wave-quantisation tail) and channel-split launch plans, reached with small
@@ -132,9 +132,11 @@ def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n,
     b = rng.integers(-4, 5, cout).astype(np.float32)
     r = f16(rng.integers(-5, 6, (n, h, w, cout)).astype(np.float32))
     single = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
+    assert eng.last_conv_launches() == 1
     os.environ["YH_PLAN_CUS"] = "4"
     try:
         split = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
+        assert eng.last_conv_launches() == 2          # the plan under test was really taken
     finally:
         os.environ.pop("YH_PLAN_CUS")
     yo = oracle.conv2d(x, wt, b, 1, k // 2, r, 1, f16=True)
@@ -153,6 +155,7 @@ def test_conv_two_phase_plan_is_bitwise_identical_on_random_data(eng):
     os.environ["YH_PLAN_CUS"] = "4"
     try:
         split = eng.op_conv2d(x, wt, b, 1, 1, None, 1)
+        assert eng.last_conv_launches() == 2
     finally:
         os.environ.pop("YH_PLAN_CUS")
     assert np.array_equal(single, split)

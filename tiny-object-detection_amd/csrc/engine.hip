@@ -134,6 +134,7 @@ struct yh_engine {
 
     bool weights_loaded = false;
     int cur_n = 0;
+    int last_conv_launches = 0;   // yh_debug_last_conv_launches
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
@@ -547,14 +548,15 @@ int tail_split_tiles(int coutPad, const ConvParams& p, ConvTile tile) {
     return mt1 >= 1 && mt1 < m_tiles ? mt1 : 0;
 }
 
-hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream) {
+hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
+    if (n_launches) *n_launches = 2;
     // channel split: 384 padded output channels (the shared head's 351) = one 256-wide tile on the
     // fastest kernel + one 128-wide tile, instead of three 128-wide ones. A/B switch: YH_CHSPLIT=0.
     static const int chsplit = getenv("YH_CHSPLIT") ? atoi(getenv("YH_CHSPLIT")) : 1;
     const int mt256 = (p.M + 255) / 256, cus = plan_cus();
     // (only where the 256-wide launch's last round is reasonably full: it runs one workgroup per CU)
     const bool rounds_ok = mt256 >= 4 * cus || mt256 % cus == 0 || mt256 % cus > cus / 2;
-    if (chsplit && tile == TILE_128x256 && coutPad == 384 && p.k_slices == 1 && mt256 >= cus * 3 / 4 && rounds_ok) {
+    if (chsplit && tile == TILE_128x256 && coutPad == 384 && p.k_slices <= 1 && mt256 >= cus * 3 / 4 && rounds_ok) {
         ConvParams a = p, b = p;
         a.n_ch_tiles = 1;
         hipError_t e = launch_conv(a, TILE_256x256_M16, stream);
@@ -563,7 +565,7 @@ hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, 
         return launch_conv(b, TILE_128x256, stream);
     }
     const int mt1 = tail_split_tiles(coutPad, p, tile);
-    if (mt1 == 0) return launch_conv(p, tile, stream);
+    if (mt1 == 0) { if (n_launches) *n_launches = 1; return launch_conv(p, tile, stream); }
     // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles whose
     // 16x16x32 MFMA form accumulates every output element in the same order as the big tile does,
     // so a row's bits do not depend on which phase computed it
@@ -1212,6 +1214,8 @@ int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, 
     return YH_OK;
 }
 
+int yh_debug_last_conv_launches(const yh_engine* h) { return h ? h->last_conv_launches : 0; }
+
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;
     auto it = h->named.find(name);
@@ -1351,7 +1355,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
         p.N = n; p.H = hh; p.W = ww; p.C = cs; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
         p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad; p.ksteps = Kpad / 64; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
         p.act = act == 1 ? 1 : 0; p.tanh_from = act == 2 ? 0 : INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile);
-        e = launch_conv_planned(p, tile, coutPad, h->stream);
+        e = launch_conv_planned(p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(ys.data(), dy, ys.size() * 2, hipMemcpyDeviceToHost);

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("yh_tfl_tensor_read", _i, [_vp, _i, _vp, _sz]),
     ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
+    ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     ("yh_op_maxpool3x3s2_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -276,6 +277,9 @@ class Engine:
         ms = C.c_float()
         self._chk(self.L.yh_time_steps(self.h, 1 if with_tail else 0, steps, C.byref(ms)))
         return ms.value
+
+    def last_conv_launches(self):
+        return self.L.yh_debug_last_conv_launches(self.h)
 
     # ---- single ops (tests)
     def op_conv2d(self, x, w, bias, stride=1, pad=0, residual=None, act=0):
