@@ -219,7 +219,8 @@ int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, in
 
 /* Test hook: copies the named intermediate tensor of the last forward (layer names of DESIGN.md:
  * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
- * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. */
+ * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. "stem" is
+ * fused into the pool kernel and only materialised by engines created with use_graph = 0 (YH_ESTATE otherwise). */
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst_host, size_t nfloats, int32_t dims[4]);
 /* Test hook: number of conv kernel launches the last yh_op_conv2d_f16 on this handle was planned as
  * (1 = single launch, 2 = two-phase or channel-split plan; the split-K reduce is not counted). */
@@ -241,6 +242,11 @@ int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, i
 /* 3x3 stride-2 pad-1 max pool of an NHWC f16 tensor. */
 int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww,
                            int32_t c, uint16_t* y);
+/* The fused stem (conv 7x7 stride 2 pad 3, 3 -> 64, bias, ReLU; then max pool 3x3 stride 2 pad 1) on
+ * x[n][S][S][3] f16 bits with w[64][7][7][3]; S even. Writes pool_out[n][PO][PO][64] and, if not NULL,
+ * stem_out[n][SO][SO][64] (the pre-pool tensor, a test hook). */
+int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                        uint16_t* stem_out, uint16_t* pool_out);
 /* Detection tail alone on caller-provided head outputs (host f16 bits, layouts as outputs 0..3)
  * for n frames; results are then read with yh_read_detections. Lets the tail be checked
  * bit-for-bit against the oracle on identical inputs. */

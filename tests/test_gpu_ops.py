@@ -161,6 +161,35 @@ def test_conv_two_phase_plan_is_bitwise_identical_on_random_data(eng):
     assert np.array_equal(single, split)
 
 
+@pytest.mark.parametrize("n,S", [(1, 16), (2, 30), (1, 64), (3, 34), (1, 96)])
+def test_stem_pool_fused_exact_on_integers(eng, oracle, n, S):
+    """Fused 7x7/2 stem + 3x3/2 max pool on small integers (every partial sum exact): the pre-pool
+    tensor it can emit and the pooled tensor must equal the oracle's conv2d -> maxpool bit for bit.
+    Sizes cover one tile, ragged tile edges (PO % 8 != 0), several images, and the image borders
+    where stem pixels and pool taps fall outside."""
+    rng = np.random.default_rng(S)
+    x = rng.integers(-4, 5, (n, S, S, 3)).astype(np.float32)
+    wt = rng.integers(-3, 4, (64, 7, 7, 3)).astype(np.float32)
+    b = rng.integers(-30, 31, 64).astype(np.float32)
+    stem, pool = eng.op_stem_pool(x, wt, b)
+    so = oracle.conv2d(x, wt, b, 2, 3, None, 1, f16=True)
+    assert np.array_equal(stem, so)
+    assert np.array_equal(pool, oracle.maxpool3x3s2(so))
+    _, pool2 = eng.op_stem_pool(x, wt, b, want_stem=False)     # production form: no stem output
+    assert np.array_equal(pool2, pool)
+
+
+def test_stem_pool_fused_vs_oracle_random(eng, oracle):
+    rng = np.random.default_rng(5)
+    x = f16(rng.normal(0, 1.2, (2, 70, 70, 3)))
+    wt = f16(rng.normal(0, 1, (64, 7, 7, 3)) / 12)
+    b = rng.normal(0, 0.2, 64).astype(np.float32)
+    stem, pool = eng.op_stem_pool(x, wt, b)
+    so = oracle.conv2d(x, wt, b, 2, 3, None, 1, f16=True)
+    assert np.abs(stem - so).max() <= 2.0 ** -10 * max(1.0, np.abs(so).max()) + 1e-3
+    assert np.array_equal(pool, oracle.maxpool3x3s2(stem))       # the pool of ITS stem is exact
+
+
 @pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))

@@ -726,6 +726,138 @@ __global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stem_pool_f16 — the stem (7x7 stride 2, 3 -> 64, bias, ReLU) fused with the 3x3 stride-2 max pool.
+// Unfused, the stem writes 64 channels at 275 x 275 per frame (9.7 MB) only for the pool to read
+// them back and keep a quarter; fused, the block keeps its stem pixels in LDS and only the pooled
+// tensor goes to HBM. The implicit GEMM also stops paying for im2col: the block stages the INPUT
+// patch once (39 x 40 pixels of 8 bytes for 17 x 17 stem pixels) and every B fragment is one
+// aligned ds_read_b128 out of it - k-step r of the 16x16x32 MFMA is kernel row r, its 32 K values
+// the 8 pixel columns x 4 stored channels right of (2 sy + r, 2 sx), which are contiguous in the
+// patch (the 8th column and the 4th channel carry zero weights).
+// One workgroup = 8 x 8 pooled pixels = 17 x 17 stem pixels (one halo row and column recomputed:
+// 13 % more MFMAs), 8 waves = 4 walkers over the 16-pixel groups x 2 channel halves; each wave keeps
+// its weight fragments (2 channel tiles x 7 rows) in registers for the whole launch; the grid is
+// persistent.
+// Border: stem pixels outside the image are staged as 0, which max() ignores because every real
+// stem pixel is >= 0 after the ReLU (the pool's padding is "absent", as in the oracle).
+// ------------------------------------------------------------------------------------------------
+#define SP_PT 8                 // pooled tile edge
+#define SP_ST (2 * SP_PT + 1)   // stem tile edge (17)
+#define SP_NPX (SP_ST * SP_ST)  // 289
+#define SP_PR (2 * SP_ST + 5)   // input patch rows (39)
+#define SP_PC 40                // input patch columns (39 used), 8 bytes each
+#define SP_SS 144               // staging row stride in bytes (64 ch f16 = 128 + 16: conflict-free 8-byte column writes)
+__global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) {
+    __shared__ __attribute__((aligned(16))) char patch[SP_PR * SP_PC * 8];
+    __shared__ __attribute__((aligned(16))) char stage[SP_NPX * SP_SS];
+    typedef float accv __attribute__((ext_vector_type(4)));
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lh = lane >> 4;
+    const int wp = wave >> 1, ct0 = (wave & 1) * 2;   // 8 waves: 4 pixel-group walkers x 2 channel halves
+
+    half8 a[2][7];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) a[ct][r] = *(const half8*)(p.w + ((ct0 + ct) * 16 + l15) * 256 + r * 32 + lh * 8);
+    f32x4 bias4[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bias4[ct] = *(const f32x4*)(p.bias + (ct0 + ct) * 16 + 4 * lh);
+
+    const int tiles_img = p.tiles_y * p.tiles_x, total = p.n * tiles_img;
+    constexpr int NCH = SP_PR * (SP_PC / 2), NLD = (NCH + 511) / 512;   // 16-byte patch chunks, per-thread slots
+    half8 nv[NLD];
+    // the next tile's patch travels through registers: loads are issued before this tile's MFMA
+    // phase and land in LDS after it, so their latency hides under the compute
+    auto fetch_patch = [&](int tile) {
+        const int b = tile / tiles_img, rem = tile - b * tiles_img;
+        const int by0 = 4 * ((rem / p.tiles_x) * SP_PT) - 2, bx0 = 4 * ((rem % p.tiles_x) * SP_PT) - 2;   // even column
+        const half_t* img = p.x + (long long)b * p.x_img_stride;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
+            const int gy = by0 + row, gx = bx0 + 2 * cp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nv[k][e] = (half_t)0.0f;
+            if (i < NCH && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp) nv[k] = *(const half8*)(img + ((long long)gy * p.Wp + gx) * 4);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
+            if (i < NCH) *(half8*)(patch + (row * SP_PC + 2 * cp) * 8) = nv[k];
+        }
+    };
+    if ((int)blockIdx.x < total) { fetch_patch(blockIdx.x); store_patch(); }
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int b = tile / tiles_img, rem = tile - b * tiles_img;
+        const int py0 = (rem / p.tiles_x) * SP_PT, px0 = (rem % p.tiles_x) * SP_PT;
+        const int next = tile + gridDim.x;
+        __syncthreads();   // patch visible; the previous tile's pool phase is done with the staging image
+        if (next < total) fetch_patch(next);
+        for (int mt = wp; mt < (SP_NPX + 15) / 16; mt += 4) {
+            const int m = mt * 16 + l15;
+            const bool in_tile = m < SP_NPX;
+            const int mi = in_tile ? m / SP_ST : SP_ST - 1, mj = in_tile ? m - mi * SP_ST : SP_ST - 1;
+            accv acc[2];   // start from the bias: one rounding fewer than (sum) + bias, and no separate add
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ct][e] = bias4[ct][e];
+            const char* bp = patch + ((2 * mi) * SP_PC + 2 * mj + 2 * lh) * 8;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const half8 bf = *(const half8*)(bp + r * SP_PC * 8);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma_f16<16>(a[ct][r], bf, acc[ct]);
+            }
+            const int sy = 2 * py0 - 1 + mi, sx = 2 * px0 - 1 + mj;
+            const bool ok = in_tile && (unsigned)sy < (unsigned)p.SO && (unsigned)sx < (unsigned)p.SO;
+            if (in_tile) {
+                half4 zero4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zero4[e] = (half_t)0.0f;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    // ReLU after the f16 rounding (rounding is monotonic and keeps 0): two packed ops
+                    half4 o = __builtin_convertvector(acc[ct], half4);
+                    o = __builtin_elementwise_max(o, zero4);
+                    o = ok ? o : zero4;
+                    *(half4*)(stage + m * SP_SS + ((ct0 + ct) * 16 + 4 * lh) * 2) = o;
+                    // test hook: each stem pixel is owned by the tile that holds it off the halo row / column
+                    if (p.stem && ok && mi >= 1 && mj >= 1)
+                        *(half4*)(p.stem + (long long)b * p.stem_img_stride + ((long long)sy * p.SO + sx) * 64 + (ct0 + ct) * 16 + 4 * lh) = o;
+                }
+            }
+        }
+        __syncthreads();
+        if (next < total) store_patch();   // nobody reads the patch any more
+        for (int wq = tid; wq < SP_PT * SP_PT * 8; wq += 512) {
+            const int pp = wq >> 3, cg = wq & 7, ly = pp / SP_PT, lx = pp - ly * SP_PT;
+            const int gy = py0 + ly, gx = px0 + lx;
+            if (gy < p.PO && gx < p.PO) {
+                half8 mx = *(const half8*)(stage + ((2 * ly) * SP_ST + 2 * lx) * SP_SS + cg * 16);
+#pragma unroll
+                for (int d = 1; d < 9; ++d) {
+                    const half8 v = *(const half8*)(stage + ((2 * ly + d / 3) * SP_ST + 2 * lx + d % 3) * SP_SS + cg * 16);
+                    mx = __builtin_elementwise_max(mx, v);
+                }
+                *(half8*)(p.pool + (long long)b * p.pool_img_stride + ((long long)gy * p.PO + gx) * 64 + cg * 8) = mx;
+            }
+        }
+    }
+}
+
+hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t stream) {
+    const long long total = (long long)p.n * p.tiles_y * p.tiles_x;
+    if (total < 1 || (p.Wp & 1)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total < 1024 ? total : 1024);   // persistent: weight fragments are loaded once per workgroup
+    hipLaunchKernelGGL(stem_pool_f16, dim3(grid), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
 // Sums the split-K partial slabs in slice order, then the usual epilogue. One lane = 8 channels of
 // one output row: 32-byte f32 reads per slice, one 16-byte f16 store.
 __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {

@@ -47,7 +47,7 @@ struct Buf {               // dense NHWC f16 tensor [max_batch][h][w][c] or a sl
     half_t* zero = nullptr;        // 16-byte zero block at the end of the owning allocation
 };
 
-enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_BILINEAR };
+enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_BILINEAR, OP_STEMPOOL };
 
 struct Op {
     OpKind kind;
@@ -135,6 +135,7 @@ struct yh_engine {
     bool weights_loaded = false;
     int cur_n = 0;
     int last_conv_launches = 0;   // yh_debug_last_conv_launches
+    bool stem_fused = false;
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
@@ -281,6 +282,20 @@ int build_graph_spec(yh_engine* h) {
     Buf stem, pool;
     if ((rc = new_buf(h, "stem", H1, H1, 64, &stem))) return rc;
     if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
+    // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or YH_STEMFUSE=0; the
+    // "stem" tensor is then only materialised for eager engines (use_graph = 0), as a test hook.
+    static const int stemfuse = getenv("YH_STEMFUSE") ? atoi(getenv("YH_STEMFUSE")) : 1;
+    h->stem_fused = stemfuse && (S % 2 == 0);
+    if (h->stem_fused) {
+        Op o;
+        o.kind = OP_STEMPOOL; o.name = "pool"; o.label = "stem_pool_f16:stem+pool";
+        o.panel = add_panel(h, { ci++ });
+        o.in = h->in_f16; o.out = pool; o.res = stem;   // res = optional stem output
+        o.P = H2; o.Q = H2;
+        o.flops_per_img = 2.0 * H1 * H1 * 64 * 147.0;
+        o.bytes_per_img = 8.0 * h->in_hp * h->in_hp + 2.0 * 64 * H2 * H2;
+        h->ops.push_back(o);
+    } else {
     {
         // the stem reads the physically padded image: pad = 0 there, output geometry from S
         Op o = conv_op(h, "stem", add_panel(h, { ci++ }), h->in_f16, stem, 2, 0, 1, nullptr);
@@ -294,6 +309,7 @@ int build_graph_spec(yh_engine* h) {
         o.P = H2; o.Q = H2;
         o.bytes_per_img = 2.0 * 64 * ((double)H1 * H1 + (double)H2 * H2);
         h->ops.push_back(o);
+    }
     }
     Buf x = pool, cfeat[4];
     char nm[32];
@@ -649,6 +665,17 @@ int launch_op(yh_engine* h, const Op& o, int n) {
         case OP_BILINEAR:
             e = launch_bilinear(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream);
             break;
+        case OP_STEMPOOL: {
+            const Panel& pn = h->panels[o.panel];
+            StemPoolParams sp;
+            sp.x = o.in.d; sp.w = pn.w; sp.bias = pn.bias; sp.pool = o.out.d;
+            sp.stem = h->cfg.use_graph ? nullptr : o.res.d;
+            sp.n = n; sp.Hp = o.in.h; sp.Wp = o.in.w; sp.SO = o.res.h; sp.PO = o.out.h;
+            sp.tiles_y = (o.out.h + 7) / 8; sp.tiles_x = (o.out.w + 7) / 8;
+            sp.x_img_stride = o.in.img_stride; sp.pool_img_stride = o.out.img_stride; sp.stem_img_stride = o.res.img_stride;
+            e = launch_stem_pool(sp, h->stream);
+            break;
+        }
     }
     if (e != hipSuccess) return h->fail(YH_EHIP, o.label + ": " + hipGetErrorString(e));
     return YH_OK;
@@ -1221,6 +1248,8 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
+    if (h->stem_fused && h->cfg.use_graph && strcmp(name, "stem") == 0)
+        return h->fail(YH_ESTATE, "the stem tensor is fused away; it is only materialised with use_graph = 0");
     const Buf& b = it->second;
     const int n = h->cur_n;
     const size_t per = (size_t)b.h * b.w * b.c;
@@ -1395,6 +1424,49 @@ int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t h
     if (e == hipSuccess) e = hipMemcpy(y, dy, no * 2, hipMemcpyDeviceToHost);
     hipFree(dx); hipFree(dy);
     if (e != hipSuccess) return h->fail(YH_EHIP, std::string("maxpool op: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                        uint16_t* stem_out, uint16_t* pool_out) {
+    if (!h || !x || !w || !bias || !pool_out || n < 1 || S < 8 || (S & 1)) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int Hp = S + 8, SO = out_dim(S, 7, 2, 3), PO = out_dim(SO, 3, 2, 1);
+    // host-side staging, as the engine does it: zero-bordered 4-channel image, stem panel [64][256]
+    std::vector<uint16_t> xs((size_t)n * Hp * Hp * 4, 0), wp((size_t)64 * 256, 0);
+    for (int b = 0; b < n; ++b)
+        for (int yy = 0; yy < S; ++yy)
+            for (int xx = 0; xx < S; ++xx)
+                memcpy(&xs[(((size_t)b * Hp + yy + 3) * Hp + xx + 3) * 4], &x[(((size_t)b * S + yy) * S + xx) * 3], 6);
+    for (int o = 0; o < 64; ++o)
+        for (int r = 0; r < 7; ++r)
+            for (int sx = 0; sx < 7; ++sx)
+                for (int c = 0; c < 3; ++c) wp[(size_t)o * 256 + r * 32 + sx * 4 + c] = w[(((size_t)o * 7 + r) * 7 + sx) * 3 + c];
+    const size_t ns = (size_t)n * SO * SO * 64, np = (size_t)n * PO * PO * 64;
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *ds = nullptr, *dp = nullptr;
+    hipError_t e = hipMalloc(&dx, xs.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&dw, wp.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&db, 64 * 4);
+    if (e == hipSuccess) e = hipMalloc(&ds, ns * 2);
+    if (e == hipSuccess) e = hipMalloc(&dp, np * 2);
+    if (e == hipSuccess) e = hipMemcpy(dx, xs.data(), xs.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dw, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, bias, 64 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(ds, 0xFF, ns * 2);   // NaN pattern: an unwritten stem pixel shows
+    if (e == hipSuccess) e = hipMemset(dp, 0xFF, np * 2);
+    if (e == hipSuccess) {
+        StemPoolParams sp;
+        sp.x = (const half_t*)dx; sp.w = (const half_t*)dw; sp.bias = (const float*)db; sp.pool = (half_t*)dp;
+        sp.stem = stem_out ? (half_t*)ds : nullptr;
+        sp.n = n; sp.Hp = Hp; sp.Wp = Hp; sp.SO = SO; sp.PO = PO; sp.tiles_y = (PO + 7) / 8; sp.tiles_x = (PO + 7) / 8;
+        sp.x_img_stride = (long long)Hp * Hp * 4; sp.pool_img_stride = (long long)PO * PO * 64; sp.stem_img_stride = (long long)SO * SO * 64;
+        e = launch_stem_pool(sp, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && stem_out) e = hipMemcpy(stem_out, ds, ns * 2, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pool_out, dp, np * 2, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dw); hipFree(db); hipFree(ds); hipFree(dp);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("stem+pool op: ") + hipGetErrorString(e));
     return YH_OK;
 }
 

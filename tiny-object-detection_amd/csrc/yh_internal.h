@@ -56,6 +56,18 @@ int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
 
+// Fused stem: 7x7 stride-2 conv (3 -> 64 channels, bias, ReLU) + 3x3 stride-2 max pool, one kernel.
+struct StemPoolParams {
+    const half_t* x;      // [n][Hp][Wp][4] f16, image at (+3, +3) inside a zero border (preprocess_rgb8_f16)
+    const half_t* w;      // stem panel [64][256]: K index = r * 32 + s * 4 + c, zero for s == 7, c == 3, r == 7
+    const float* bias;    // [64]
+    half_t* pool;         // [n][PO][PO][64]
+    half_t* stem;         // optional [n][SO][SO][64] (test hook; nullptr in production runs)
+    int n, Hp, Wp, SO, PO, tiles_y, tiles_x;
+    long long x_img_stride, pool_img_stride, stem_img_stride;
+};
+hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // Element-wise / gather kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------------

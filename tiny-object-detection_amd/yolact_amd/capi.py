@@ -85,6 +85,7 @@ SYMBOLS = [
     ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
+    ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     ("yh_op_maxpool3x3s2_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -308,6 +309,19 @@ class Engine:
         y = np.zeros((n, ho, wo, c), np.uint16)
         self._chk(self.L.yh_op_maxpool3x3s2_f16(self.h, _p(xb), n, hh, ww, c, _p(y)))
         return _bits_f32(y, y.shape)
+
+    def op_stem_pool(self, x, w, bias, want_stem=True):
+        """x [n][S][S][3], w [64][7][7][3] (f16-representable f32) -> (stem or None, pool) as f32 NHWC."""
+        n, S = x.shape[0], x.shape[1]
+        so = (S + 6 - 7) // 2 + 1
+        po = (so + 2 - 3) // 2 + 1
+        xb, wb = _f16_bits(x), _f16_bits(w)
+        bias = np.ascontiguousarray(bias, np.float32)
+        stem = np.zeros((n, so, so, 64), np.uint16) if want_stem else None
+        pool = np.zeros((n, po, po, 64), np.uint16)
+        self._chk(self.L.yh_op_stem_pool_f16(self.h, _p(xb), n, S, _p(wb), _p(bias), _p(stem) if want_stem else None, _p(pool)))
+        f = lambda a: a.view(np.float16).astype(np.float32)
+        return (f(stem) if want_stem else None), f(pool)
 
     def op_detect(self, loc, conf, mask, proto):
         n = loc.shape[0]
