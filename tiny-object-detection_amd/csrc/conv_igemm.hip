@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     constexpr int LDS_BYTES = cmax<RING_BYTES, (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
     static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
-    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 5) && !SMALLC), "ring variants: no ordinary loads may share the loop");
+    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4 || STAGES == 5) && !SMALLC), "ring variants: no ordinary loads may share the loop");
     static_assert(STAGES != 5 || !SPLITK, "X3W2 has no split-K form");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -354,31 +354,41 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             __builtin_amdgcn_s_setprio(0);
         };
         const int nk = nk_total;
-        load_tile(0);
-        if (nk > 1) load_tile(1);
-        if (nk > 2) load_tile(2);
-        // tile 0 landed: at most min(nk-1, 2) younger tiles may stay in flight
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int RS = STAGES;   // ring size (3 or 4): RS - 1 tiles in flight after the prologue, RS - 2 across a step
+        // waits until all but the `younger` most recently issued tiles have landed (compile-time immediates)
+        auto wait_younger = [&](int younger) {
+            if (younger >= 2 && RS >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#pragma unroll
+        for (int t = 0; t < RS; ++t)
+            if (t < nk) load_tile(t);
+        // tile 0 landed: at most min(nk, RS) - 1 younger tiles may stay in flight
+        {
+            const int younger = (nk < RS ? nk : RS) - 1;
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else wait_younger(younger);
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         Frag f0, f1;
         read_frags(0, f0);
-        int st1 = 1, st0 = 0;  // stage of tile kt+1, stage of tile kt (refilled with tile kt+3)
+        int st1 = 1, st0 = 0;  // stage of tile kt+1, stage of tile kt (refilled with tile kt+RS)
         auto step = [&](int kt, Frag& cur, Frag& nxt) {
-            if (kt + 1 < nk) {  // tile kt+1 landed; only tile kt+2 may still be in flight
-                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 1 < nk) {  // tile kt+1 landed; tiles kt+2 .. kt+RS-1 (those that exist) may still be in flight
+                const int rest = nk - kt - 2;
+                wait_younger(rest < RS - 2 ? rest : RS - 2);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of tile kt are in registers
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 3 < nk) load_tile(st0);
+            if (kt + RS < nk) load_tile(st0);
             if (kt + 1 < nk) read_frags(st1, nxt);
             mfma_frags(cur);
-            st0 = st0 == 2 ? 0 : st0 + 1;
-            st1 = st1 == 2 ? 0 : st1 + 1;
+            st0 = st0 == RS - 1 ? 0 : st0 + 1;
+            st1 = st1 == RS - 1 ? 0 : st1 + 1;
         };
         int kt = 0;
         for (; kt + 1 < nk; kt += 2) {
@@ -904,12 +914,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
                  case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_X3: case TILE_ROWPATCH_256: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -927,20 +937,27 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_ROWPATCH_256: return "conv_rowpatch_f16<256,2>";
         case TILE_ROWPATCH_128: return "conv_rowpatch_f16<128,1>";
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
+        case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
     }
     return "?";
 }
 
+hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream) {
+    const long long work = (long long)p.M * (p.cout8 >> 3);
+    hipLaunchKernelGGL(splitk_reduce_f16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// One kernel launch (for split-K: the main kernel only).
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm - p.m_tile0;
     if (n_m_tiles < 1) return hipErrorInvalidValue;
-    if (p.k_slices > 1) {
-        if (tile != TILE_128x128_S3) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), dim3((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices)),
-                           dim3(256), 0, stream, p);
-        const long long work = (long long)p.M * (p.cout8 >> 3);
-        hipLaunchKernelGGL(splitk_reduce_f16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p);
+    if (p.k_slices > 1) {   // split-K main kernel; launch_splitk_reduce finishes it
+        const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
+        if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);
+        else if (tile == TILE_128x128_S4) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1, true>), gk, dim3(256), 0, stream, p);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
@@ -952,6 +969,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_ROWPATCH_256: hipLaunchKernelGGL((conv_rowpatch_f16<256, 2, 3>), grid, dim3(512), 0, stream, p); break;

@@ -502,6 +502,8 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
     // A/B switch (tools/): the 16x16x32 forms of the 128 x 128 tiles everywhere
     static const int small16 = getenv("YH_SMALL16") ? atoi(getenv("YH_SMALL16")) : 0;
     const ConvTile t = pick_tile_base(pn, M, stride, pad);
+    static const int s4 = getenv("YH_S4") ? atoi(getenv("YH_S4")) : 0;   // A/B switch (tools/): ring of four for the latency-bound tile
+    if (s4 && t == TILE_128x128_S3) return TILE_128x128_S4;
     if (small16 && t == TILE_128x128) return TILE_128x128_M16;
     if (small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
     return t;
@@ -564,35 +566,58 @@ int tail_split_tiles(int coutPad, const ConvParams& p, ConvTile tile) {
     return mt1 >= 1 && mt1 < m_tiles ? mt1 : 0;
 }
 
-hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
-    if (n_launches) *n_launches = 2;
+// A convolution is planned as one to two kernel launches; `frac` is the share of the op's
+// algorithmic work a launch does (profile attribution), `what` a label suffix.
+struct KLaunch { bool reduce; ConvParams p; ConvTile tile; double frac; const char* what; };
+
+int plan_conv(const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
+    if (p.k_slices > 1) {   // split-K: main kernel + slab reduction
+        out[0] = KLaunch{ false, p, tile, 1.0, "/splitk" };
+        out[1] = KLaunch{ true, p, tile, 0.0, "" };
+        return 2;
+    }
     // channel split: 384 padded output channels (the shared head's 351) = one 256-wide tile on the
     // fastest kernel + one 128-wide tile, instead of three 128-wide ones. A/B switch: YH_CHSPLIT=0.
     static const int chsplit = getenv("YH_CHSPLIT") ? atoi(getenv("YH_CHSPLIT")) : 1;
     const int mt256 = (p.M + 255) / 256, cus = plan_cus();
     // (only where the 256-wide launch's last round is reasonably full: it runs one workgroup per CU)
     const bool rounds_ok = mt256 >= 4 * cus || mt256 % cus == 0 || mt256 % cus > cus / 2;
-    if (chsplit && tile == TILE_128x256 && coutPad == 384 && p.k_slices <= 1 && mt256 >= cus * 3 / 4 && rounds_ok) {
+    if (chsplit && tile == TILE_128x256 && coutPad == 384 && mt256 >= cus * 3 / 4 && rounds_ok) {
         ConvParams a = p, b = p;
         a.n_ch_tiles = 1;
-        hipError_t e = launch_conv(a, TILE_256x256_M16, stream);
-        if (e != hipSuccess) return e;
         b.n_ch_tiles = 1; b.ch_tile0 = 2;
-        return launch_conv(b, TILE_128x256, stream);
+        out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
+        out[1] = KLaunch{ false, b, TILE_128x256, 128.0 / 384.0, "/ch256-383" };
+        return 2;
     }
     const int mt1 = tail_split_tiles(coutPad, p, tile);
-    if (mt1 == 0) { if (n_launches) *n_launches = 1; return launch_conv(p, tile, stream); }
+    if (mt1 == 0) { out[0] = KLaunch{ false, p, tile, 1.0, "" }; return 1; }
     // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles whose
     // 16x16x32 MFMA form accumulates every output element in the same order as the big tile does,
     // so a row's bits do not depend on which phase computed it
     ConvParams a = p, b = p;
     a.M = mt1 * conv_tile_m(tile);
-    hipError_t e = launch_conv(a, tile, stream);
-    if (e != hipSuccess) return e;
     b.m_tile0 = a.M / 128;
     b.n_ch_tiles = coutPad / 128;
     const long long tb = (long long)((p.M - a.M + 127) / 128) * b.n_ch_tiles;
-    return launch_conv(b, tb <= plan_cus() ? TILE_128x128_S3_M16 : TILE_128x128_M16, stream);
+    out[0] = KLaunch{ false, a, tile, (double)a.M / p.M, "/rounds" };
+    out[1] = KLaunch{ false, b, tb <= plan_cus() ? TILE_128x128_S3_M16 : TILE_128x128_M16, (double)(p.M - a.M) / p.M, "/tail" };
+    return 2;
+}
+
+hipError_t launch_k(const KLaunch& k, hipStream_t stream) {
+    return k.reduce ? launch_splitk_reduce(k.p, stream) : launch_conv(k.p, k.tile, stream);
+}
+
+hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
+    KLaunch k[2];
+    const int nk = plan_conv(p, tile, coutPad, k);
+    if (n_launches) *n_launches = p.k_slices > 1 ? 1 : nk;   // (the split-K reduce is not counted: include/yolact_hip.h)
+    for (int i = 0; i < nk; ++i) {
+        const hipError_t e = launch_k(k[i], stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
@@ -625,7 +650,8 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad);
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
-    if (tile == TILE_128x128_S3 && p.ksteps >= 8) {
+    static const int splitk_min = getenv("YH_SPLITK_MINSTEPS") ? atoi(getenv("YH_SPLITK_MINSTEPS")) : 12;   // A/B switch (tools/)
+    if ((tile == TILE_128x128_S3 || tile == TILE_128x128_S4) && p.ksteps >= splitk_min) {
         // few tiles, long K: split K so that about one workgroup per CU streams the weights
         const long long tiles = (long long)((p.M + 127) / 128) * p.n_ch_tiles;
         int sl = (int)(256 / tiles);
@@ -1269,26 +1295,57 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
 }
 
 // ---- measurement hooks -------------------------------------------------------------------------
+// One profile entry per KERNEL launch (so that the averages agree with rocprofv3's per-kernel stats):
+// a conv op planned as two launches (wave-quantisation tail, channel split, split-K + reduce) gives
+// two entries, its algorithmic FLOPs and bytes shared out by the rows / channels each launch covers.
+struct ProfEntry { int op; int stage; KLaunch k; bool is_conv; };
+
+static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector<ProfEntry>* out) {
+    out->clear();
+    for (int i = 0; i < (int)h->ops.size(); ++i) {
+        const Op& o = h->ops[i];
+        if (o.kind != OP_CONV) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }
+        ConvParams p;
+        const int rc = fill_conv_params(h, o, n, &p);
+        if (rc) return rc;
+        const Panel& pn = h->panels[o.panel];
+        KLaunch k[2];
+        const int nk = plan_conv(p, pick_tile(pn, p.M, o.stride, o.pad), pn.coutPad, k);
+        for (int j = 0; j < nk; ++j) { ProfEntry e{}; e.op = i; e.stage = -1; e.k = k[j]; e.is_conv = true; out->push_back(e); }
+    }
+    if (with_tail)
+        for (int st = 0; st < detect_launch_count(); ++st) { ProfEntry e{}; e.op = -1; e.stage = st; e.is_conv = false; out->push_back(e); }
+    return YH_OK;
+}
+
 int yh_profile_launch_count(const yh_engine* h, int32_t with_tail) {
     if (!h) return YH_EINVAL;
-    return (int)h->ops.size() + (with_tail ? detect_launch_count() : 0);
+    std::vector<ProfEntry> ent;
+    yh_engine* hm = const_cast<yh_engine*>(h);
+    if (build_profile_entries(hm, h->cur_n >= 1 ? h->cur_n : h->cfg.max_batch, with_tail, &ent)) return YH_EINVAL;
+    return (int)ent.size();
 }
 
 int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, double* flops, double* bytes, const char** names) {
     if (!h || !ms || reps < 1) return YH_EINVAL;
     if (!h->weights_loaded || h->cur_n < 1) return h->fail(YH_ESTATE, "weights and input must be set");
     HIPCHK(h, hipSetDevice(h->dev));
-    const int n = h->cur_n, nl = yh_profile_launch_count(h, with_tail), nops = (int)h->ops.size();
+    const int n = h->cur_n;
+    std::vector<ProfEntry> ent;
+    int rc = build_profile_entries(h, n, with_tail, &ent);
+    if (rc) return rc;
+    const int nl = (int)ent.size();
     std::vector<hipEvent_t> ev((size_t)nl * 2);
     for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
     std::vector<double> acc(nl, 0.0);
     h->det.n = n;
-    int rc = YH_OK;
     for (int r = 0; r < reps && rc == YH_OK; ++r) {
         for (int i = 0; i < nl && rc == YH_OK; ++i) {
+            const ProfEntry& pe = ent[i];
             hipEventRecord(ev[2 * i], h->stream);
-            if (i < nops) rc = launch_op(h, h->ops[i], n);
-            else if (launch_detect_stage(h->det, i - nops, h->stream) != hipSuccess) rc = h->fail(YH_EHIP, "detect stage launch failed");
+            if (pe.is_conv) { if (launch_k(pe.k, h->stream) != hipSuccess) rc = h->fail(YH_EHIP, "conv launch failed in profile run"); }
+            else if (pe.op >= 0) rc = launch_op(h, h->ops[pe.op], n);
+            else if (launch_detect_stage(h->det, pe.stage, h->stream) != hipSuccess) rc = h->fail(YH_EHIP, "detect stage launch failed");
             hipEventRecord(ev[2 * i + 1], h->stream);
         }
         if (rc) break;
@@ -1299,13 +1356,23 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
     if (rc) return rc;
     h->prof_labels.assign(nl, std::string());
     for (int i = 0; i < nl; ++i) {
+        const ProfEntry& pe = ent[i];
         ms[i] = (float)(acc[i] / reps);
-        const bool isop = i < nops;
-        if (isop && h->ops[i].kind == OP_CONV)  // the tile (hence the kernel symbol) is chosen per launch
-            h->prof_labels[i] = std::string(conv_tile_symbol(pick_tile(h->panels[h->ops[i].panel], n * h->ops[i].P * h->ops[i].Q, h->ops[i].stride, h->ops[i].pad))) + ":" + h->ops[i].name;
-        else h->prof_labels[i] = isop ? h->ops[i].label : detect_stage_name(i - nops);
-        if (flops) flops[i] = isop ? h->ops[i].flops_per_img * n : 0.0;
-        if (bytes) bytes[i] = isop ? h->ops[i].bytes_per_img * n + h->ops[i].bytes_fixed : 0.0;
+        double fl = 0.0, by = 0.0;
+        if (pe.op >= 0) {
+            const Op& o = h->ops[pe.op];
+            const double frac = pe.is_conv ? pe.k.frac : 1.0;
+            fl = o.flops_per_img * n * frac;
+            by = (o.bytes_per_img * n + o.bytes_fixed) * frac;
+            if (pe.is_conv && pe.k.reduce) {
+                h->prof_labels[i] = "splitk_reduce_f16:" + o.name;
+                by = (double)pe.k.p.M * pe.k.p.partial_ld * 4.0 * pe.k.p.k_slices + (double)pe.k.p.M * pe.k.p.cout8 * 2.0;
+            } else if (pe.is_conv) {
+                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + ":" + o.name + pe.k.what;
+            } else h->prof_labels[i] = o.label;
+        } else h->prof_labels[i] = detect_stage_name(pe.stage);
+        if (flops) flops[i] = fl;
+        if (bytes) bytes[i] = by;
         if (names) names[i] = h->prof_labels[i].c_str();
     }
     return YH_OK;

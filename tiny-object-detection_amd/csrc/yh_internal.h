@@ -50,11 +50,12 @@ struct ConvParams {
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8, TILE_256x256_X3 = 9, TILE_ROWPATCH_256 = 10, TILE_ROWPATCH_128 = 11,
-                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13 };
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14 };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
+hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream);
 
 // Fused stem: 7x7 stride-2 conv (3 -> 64 channels, bias, ReLU) + 3x3 stride-2 max pool, one kernel.
 struct StemPoolParams {
