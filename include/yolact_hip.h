@@ -63,7 +63,9 @@ typedef struct yh_config {
     float conf_thresh;     /* 0.05 */
     float nms_thresh;      /* 0.5 */
     int32_t use_graph;     /* 1: capture the forward in a hipGraph after the first invoke */
-    int32_t reserved[8];   /* zero */
+    int32_t debug_tensors; /* 1: also materialise tensors that production runs fuse away (the pre-pool
+                            * "stem" tensor) for yh_debug_read_tensor; 0 (default): do not */
+    int32_t reserved[7];   /* zero */
 } yh_config;
 
 /* Mirrors tflite TensorInfo {name, element_kind, dims, params{scale, zero_point}} as read at
@@ -220,7 +222,7 @@ int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, in
 /* Test hook: copies the named intermediate tensor of the last forward (layer names of DESIGN.md:
  * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
  * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. "stem" is
- * fused into the pool kernel and only materialised by engines created with use_graph = 0 (YH_ESTATE otherwise). */
+ * fused into the pool kernel and only materialised by engines created with debug_tensors = 1 (YH_ESTATE otherwise). */
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst_host, size_t nfloats, int32_t dims[4]);
 /* Test hook: number of conv kernel launches the last yh_op_conv2d_f16 on this handle was planned as
  * (1 = single launch, 2 = two-phase or channel-split plan; the split-K reduce is not counted). */

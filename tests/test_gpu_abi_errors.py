@@ -55,6 +55,10 @@ def test_call_order_and_bounds(built):
     d4 = (C.c_int32 * 4)()
     assert L.yh_debug_read_tensor(eng.h, b"no_such_layer", None, 0, C.byref(d4)) == -1
     assert b"no_such_layer" in L.yh_last_error(eng.h)
+    # the pre-pool stem tensor is fused away unless the engine was created with debug_tensors = 1
+    assert L.yh_debug_read_tensor(eng.h, b"stem", None, 0, C.byref(d4)) == -5
+    assert b"debug_tensors" in L.yh_last_error(eng.h)
+    assert L.yh_debug_read_tensor(eng.h, b"pool", None, 0, C.byref(d4)) == 0 and d4[3] == 64
     # the error of a failed call does not poison the next good one
     eng.evaluate()
     assert len(eng.detections(0)[0]) >= 0

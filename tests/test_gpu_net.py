@@ -12,7 +12,7 @@ S = 128
 @pytest.fixture(scope="module")
 def setup(built, oracle):
     import yolact_amd as ya
-    eng = ya.Engine(input_size=S, max_batch=2, use_graph=False)
+    eng = ya.Engine(input_size=S, max_batch=2, use_graph=False, debug_tensors=True)
     blob = eng.generate_weights(seed=1)
     eng.load_weights(blob)
     net = oracle.Net(50, S, 81, blob=blob)

@@ -283,7 +283,7 @@ int build_graph_spec(yh_engine* h) {
     if ((rc = new_buf(h, "stem", H1, H1, 64, &stem))) return rc;
     if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
     // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or YH_STEMFUSE=0; the
-    // "stem" tensor is then only materialised for eager engines (use_graph = 0), as a test hook.
+    // "stem" tensor is then only materialised for engines created with debug_tensors = 1 (test hook).
     static const int stemfuse = getenv("YH_STEMFUSE") ? atoi(getenv("YH_STEMFUSE")) : 1;
     h->stem_fused = stemfuse && (S % 2 == 0);
     if (h->stem_fused) {
@@ -695,7 +695,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             const Panel& pn = h->panels[o.panel];
             StemPoolParams sp;
             sp.x = o.in.d; sp.w = pn.w; sp.bias = pn.bias; sp.pool = o.out.d;
-            sp.stem = h->cfg.use_graph ? nullptr : o.res.d;
+            sp.stem = h->cfg.debug_tensors ? o.res.d : nullptr;
             sp.n = n; sp.Hp = o.in.h; sp.Wp = o.in.w; sp.SO = o.res.h; sp.PO = o.out.h;
             sp.tiles_y = (o.out.h + 7) / 8; sp.tiles_x = (o.out.w + 7) / 8;
             sp.x_img_stride = o.in.img_stride; sp.pool_img_stride = o.out.img_stride; sp.stem_img_stride = o.res.img_stride;
@@ -919,7 +919,7 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     if ((cfg->backbone != YH_BACKBONE_R50 && cfg->backbone != YH_BACKBONE_R101) || cfg->input_size < 64 ||
         cfg->input_size > 1024 || cfg->max_batch < 1 || cfg->max_batch > 256 || cfg->num_classes < 5 ||
         cfg->num_classes > 81 || cfg->top_k < 1 || cfg->top_k > 256 || cfg->max_dets < 1 || cfg->max_dets > 128 ||
-        (cfg->num_classes - 1) * cfg->top_k > 16384) {
+        (cfg->num_classes - 1) * cfg->top_k > 16384 || (cfg->debug_tensors != 0 && cfg->debug_tensors != 1)) {
         g_create_error = "configuration out of range";
         return YH_EINVAL;
     }
@@ -1274,8 +1274,8 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
-    if (h->stem_fused && h->cfg.use_graph && strcmp(name, "stem") == 0)
-        return h->fail(YH_ESTATE, "the stem tensor is fused away; it is only materialised with use_graph = 0");
+    if (h->stem_fused && !h->cfg.debug_tensors && strcmp(name, "stem") == 0)
+        return h->fail(YH_ESTATE, "the stem tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     const Buf& b = it->second;
     const int n = h->cur_n;
     const size_t per = (size_t)b.h * b.w * b.c;

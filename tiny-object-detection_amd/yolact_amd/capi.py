@@ -21,7 +21,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("backbone", C.c_int32),
                 ("input_size", C.c_int32), ("max_batch", C.c_int32), ("num_classes", C.c_int32),
                 ("top_k", C.c_int32), ("max_dets", C.c_int32), ("conf_thresh", C.c_float),
-                ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("debug_tensors", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class TensorInfo(C.Structure):
@@ -130,13 +130,14 @@ class Engine:
     """RAII wrapper of one yh_engine handle."""
 
     def __init__(self, input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100,
-                 conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0):
+                 conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0, debug_tensors=False):
         self.L = load_library()
         cfg = Config()
         self.L.yh_default_config(C.byref(cfg))
         cfg.device, cfg.backbone, cfg.input_size, cfg.max_batch = device, backbone, input_size, max_batch
         cfg.num_classes, cfg.top_k, cfg.max_dets = num_classes, top_k, max_dets
         cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = conf_thresh, nms_thresh, 1 if use_graph else 0
+        cfg.debug_tensors = 1 if debug_tensors else 0
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.L.yh_create(C.byref(cfg), C.byref(h))

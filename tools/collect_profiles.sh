@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "[1/6] bench"; python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 echo "[2/6] rocprofv3 kernel stats of the bench command"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-cp $(ls $OUT/stats/*kernel_stats.csv $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
+cp "$(find $OUT/stats -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats.csv
 echo "[3/6] per-launch tables"
 python3 $R/tools/profile_table.py --batch 64 > $OUT/${TAG}_hipevent_per_launch_batch64.txt
 python3 $R/tools/profile_table.py --batch 1 > $OUT/${TAG}_hipevent_per_launch_batch1.txt
@@ -20,8 +20,8 @@ echo "[4/6] PMC FETCH_SIZE"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcF -o run --output-format csv -- python3 $R/tools/pmc_run.py 64 > $OUT/pmcF.log 2>&1
 echo "[5/6] PMC WRITE_SIZE"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcW -o run --output-format csv -- python3 $R/tools/pmc_run.py 64 > $OUT/pmcW.log 2>&1
-F=$(ls $OUT/pmcF/*counter_collection.csv $OUT/pmcF/*/*counter_collection.csv 2>/dev/null | head -1)
-W=$(ls $OUT/pmcW/*counter_collection.csv $OUT/pmcW/*/*counter_collection.csv 2>/dev/null | head -1)
+F=$(find $OUT/pmcF -name "*counter_collection.csv" | sort | tail -1)
+W=$(find $OUT/pmcW -name "*counter_collection.csv" | sort | tail -1)
 python3 $R/tools/make_traffic.py $F $W 64 $OUT/${TAG}_traffic.json > /dev/null
 echo "[6/6] SQ counters"
 {
@@ -29,8 +29,8 @@ echo "[6/6] SQ counters"
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM"; do
     tag=$(echo $set | md5sum | cut -c1-6)
     rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$tag -o run --output-format csv -- python3 $R/tools/pmc_run.py 16 > $OUT/pmc_$tag.log 2>&1
-    python3 $R/tools/pmc_summary.py $(ls $OUT/pmc_$tag/*counter_collection.csv $OUT/pmc_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
+    python3 $R/tools/pmc_summary.py "$(find $OUT/pmc_$tag -name "*counter_collection.csv" | sort | tail -1)"
   done
 } > $OUT/${TAG}_pmc_kernels.txt
-rm -rf $OUT/stats $OUT/pmcF $OUT/pmcW $OUT/pmc_*/ 
+rm -rf $OUT/stats $OUT/pmcF $OUT/pmcW; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
 echo done
