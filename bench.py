@@ -238,12 +238,17 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="control-flow rehearsal of the N > 1 path on a single-GPU box: every rank uses cuda:0 and the "
+                         "weight broadcast goes over gloo (RCCL refuses two ranks on one device); not a measurement")
     a = ap.parse_args()
 
     import numpy as np
     import torch
     import yolact_amd as ya
     rank, world, local_rank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if a.rehearse_on_one_gpu:
+        local_rank = 0
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
@@ -253,7 +258,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     # weights: generated once on rank 0, replicated with ONE RCCL broadcast over xGMI
     probe = ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=1, use_graph=False, device=local_rank)
