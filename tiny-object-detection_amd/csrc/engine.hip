@@ -504,6 +504,10 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
     const ConvTile t = pick_tile_base(pn, M, stride, pad);
     static const int s4 = getenv("YH_S4") ? atoi(getenv("YH_S4")) : 0;   // A/B switch (tools/): ring of four for the latency-bound tile
     if (s4 && t == TILE_128x128_S3) return TILE_128x128_S4;
+    // 128 x 256: the 2-stage 16x16x32 form measures ~5 % faster than the 3-stage 32x32x16 ring on stride-1
+    // layers (0.112 vs 0.118 ms on the 69 x 69 3x3 convs at batch 64) and slower on the stride-2 one
+    static const int t128m16 = getenv("YH_128X256_M16") ? atoi(getenv("YH_128X256_M16")) : 1;   // A/B switch (tools/)
+    if (t128m16 && t == TILE_128x256 && stride == 1) return TILE_128x256_M16;
     if (small16 && t == TILE_128x128) return TILE_128x128_M16;
     if (small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
     return t;
@@ -582,12 +586,12 @@ int plan_conv(const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
     const int mt256 = (p.M + 255) / 256, cus = plan_cus();
     // (only where the 256-wide launch's last round is reasonably full: it runs one workgroup per CU)
     const bool rounds_ok = mt256 >= 4 * cus || mt256 % cus == 0 || mt256 % cus > cus / 2;
-    if (chsplit && tile == TILE_128x256 && coutPad == 384 && mt256 >= cus * 3 / 4 && rounds_ok) {
+    if (chsplit && (tile == TILE_128x256 || tile == TILE_128x256_M16) && coutPad == 384 && mt256 >= cus * 3 / 4 && rounds_ok) {
         ConvParams a = p, b = p;
         a.n_ch_tiles = 1;
         b.n_ch_tiles = 1; b.ch_tile0 = 2;
         out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
-        out[1] = KLaunch{ false, b, TILE_128x256, 128.0 / 384.0, "/ch256-383" };
+        out[1] = KLaunch{ false, b, tile, 128.0 / 384.0, "/ch256-383" };
         return 2;
     }
     const int mt1 = tail_split_tiles(coutPad, p, tile);
@@ -1405,6 +1409,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
     if (tile == TILE_256x256 && getenv("YH_X3") && atoi(getenv("YH_X3"))) tile = TILE_256x256_X3;
     else if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
+    if (tile == TILE_128x256 && stride == 1 && !(getenv("YH_128X256_M16") && !atoi(getenv("YH_128X256_M16")))) tile = TILE_128x256_M16;
     {   // the op test reaches the row-patch kernel the same way the engine does (no grid-size floor here)
         const int rp = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;
         if (rp && k == 3 && stride == 1 && pad == 1 && cin % 64 == 0) {
