@@ -18,6 +18,13 @@ import numpy as np
 I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
 
 
+def _f32(s):
+    """A tensor's scale is a float32 in the flatbuffer; TFLite promotes THAT value to double
+    (kernel_util.cc: static_cast<double>(input->params.scale)), so every multiplier below starts
+    from the float32-rounded scale, whatever precision the caller's Python float carries."""
+    return float(np.float32(s))
+
+
 def quantize_multiplier(m):
     """tflite::QuantizeMultiplier(double): (int32 Q31 mantissa, shift)."""
     if m == 0.0:
@@ -98,7 +105,7 @@ def conv2d_u8(x, zx, sx, w, zw, sw_, bias, zo, so, stride, padding, act, dil=(1,
     _, h, ww, ci = x.shape
     co, kh, kw, _ = w.shape
     ho, wo, ph, pw = _geom(h, ww, kh, kw, stride[0], stride[1], dil[0], dil[1], padding)
-    mult, shift = quantize_multiplier(float(sx) * float(sw_) / float(so))
+    mult, shift = quantize_multiplier(_f32(sx) * _f32(sw_) / _f32(so))
     lo, hi = act_range_u8(act, so, zo)
     xi = x[0].astype(np.int64) - zx
     wi = w.astype(np.int64) - zw
@@ -124,7 +131,7 @@ def dwconv2d_u8(x, zx, sx, w, zw, sw_, bias, zo, so, stride, padding, act, depth
     _, h, ww, ci = x.shape
     _, kh, kw, co = w.shape
     ho, wo, ph, pw = _geom(h, ww, kh, kw, stride[0], stride[1], dil[0], dil[1], padding)
-    mult, shift = quantize_multiplier(float(sx) * float(sw_) / float(so))
+    mult, shift = quantize_multiplier(_f32(sx) * _f32(sw_) / _f32(so))
     lo, hi = act_range_u8(act, so, zo)
     xi = x[0].astype(np.int64) - zx
     wi = w[0].astype(np.int64) - zw
@@ -147,10 +154,10 @@ def dwconv2d_u8(x, zx, sx, w, zw, sw_, bias, zo, so, stride, padding, act, depth
 def add_u8(a, za, sa, b, zb, sb, zo, so, act):
     """reference_ops::Add (uint8), left_shift = 20."""
     ls = 20
-    twice = 2.0 * max(float(sa), float(sb))
-    m1, s1 = quantize_multiplier(float(sa) / twice)
-    m2, s2 = quantize_multiplier(float(sb) / twice)
-    mo, so_ = quantize_multiplier(twice / ((1 << ls) * float(so)))
+    twice = 2.0 * max(_f32(sa), _f32(sb))
+    m1, s1 = quantize_multiplier(_f32(sa) / twice)
+    m2, s2 = quantize_multiplier(_f32(sb) / twice)
+    mo, so_ = quantize_multiplier(twice / ((1 << ls) * _f32(so)))
     lo, hi = act_range_u8(act, so, zo)
     v1 = mbqm((a.astype(np.int64) - za) * (1 << ls), m1, s1)
     v2 = mbqm((b.astype(np.int64) - zb) * (1 << ls), m2, s2)
@@ -160,7 +167,7 @@ def add_u8(a, za, sa, b, zb, sb, zo, so, act):
 
 def requant_u8(x, zi, si, zo, so):
     """QUANTIZE uint8 -> uint8 (reference_ops::Requantize)."""
-    m, s = quantize_multiplier(float(si) / float(so))
+    m, s = quantize_multiplier(_f32(si) / _f32(so))
     return np.clip(mbqm(x.astype(np.int64) - zi, m, s) + zo, 0, 255).astype(np.uint8)
 
 
@@ -176,7 +183,7 @@ def dequantize_u8(x, z, s):
 
 
 def relu_u8(x, zi, si, zo, so, act=1):
-    m, s = quantize_multiplier(float(si) / float(so))
+    m, s = quantize_multiplier(_f32(si) / _f32(so))
     lo, hi = act_range_u8(act, so, zo)
     return np.clip(mbqm(x.astype(np.int64) - zi, m, s) + zo, lo, hi).astype(np.uint8)
 

@@ -82,6 +82,28 @@ def test_mobilenet_like_graph_every_tensor(built):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", [11, 0])
+def test_full_size_mobilenetv2_yolact_graph(built, seed):
+    """The full-size stand-in for FRC_model.tflite (136 ops at 224x224: the op census of
+    data/FRC_model_edgetpu.log): all five outputs and a sample of intermediates against the numpy
+    oracle, bit for bit, and a second invoke (graph replay) identical to the first."""
+    rng = np.random.default_rng(seed)
+    model = M.mobilenetv2_yolact(rng)
+    x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
+    eng, val, outs = _run_both(model, x)
+    assert eng.output_count() == 5 and eng.output_info(4)["dims"] == (1, 784, 81)
+    for k, o in enumerate(model.outputs):
+        assert np.array_equal(outs[k], val[o]), model.tensors[o].name
+    written = sorted({o for op in model.ops for o in op.outputs})
+    for i in written[::7]:
+        t = model.tensors[i]
+        assert np.array_equal(eng.tensor(i, t.shape, B.NP_TYPE[t.dtype]), val[i]), (i, t.name)
+    eng.invoke()
+    for k, o in enumerate(model.outputs):
+        assert np.array_equal(eng.output(k), outs[k])
+    eng.close()
+
+
 def test_classify_through_a_tflite_model(built, oracle, golden_dir):
     """Yolact::classify (yolact.rs:192-234) with a .tflite in the middle: pre-processing, two
     invokes, output-4 dequantisation (yolact.rs:177), postprocess, stitch, resize back."""

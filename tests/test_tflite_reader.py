@@ -59,3 +59,21 @@ def test_oracle_fixed_point_primitives():
         assert np.abs(got - want).max() <= 1.0 + 1e-6        # two roundings: within one unit of exact
     assert O.mbqm(np.array([100]), 1 << 30, 1)[0] == 100     # 0.5 * 2^1
     assert O._rdbpot(np.array([5, -5, 6, -6, 7]), 2).tolist() == [1, -1, 2, -2, 2]   # ties away from zero
+
+
+def test_oracle_scales_are_float32_like_the_file():
+    """A .tflite stores scales as float32 and TFLite promotes that value to double; the oracle must
+    not see more precision than the file carries (it once did: 1-LSB differences against the GPU
+    executor on 2 of 150 528 elements of a 1x1 conv)."""
+    import tfl_oracle as O
+    sx, sw, so = 0.043721839, 0.0013810679, 0.027364615      # doubles that are not float32 values
+    for s in (sx, sw, so):
+        assert float(np.float32(s)) != s
+    a = O.quantize_multiplier(O._f32(sx) * O._f32(sw) / O._f32(so))
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (1, 6, 6, 8), dtype=np.uint8)
+    w = rng.integers(0, 256, (4, 1, 1, 8), dtype=np.uint8)
+    b = rng.integers(-100, 100, 4).astype(np.int32)
+    y1 = O.conv2d_u8(x, 120, sx, w, 128, sw, b, 110, so, (1, 1), 0, 0)
+    y2 = O.conv2d_u8(x, 120, float(np.float32(sx)), w, 128, float(np.float32(sw)), b, 110, float(np.float32(so)), (1, 1), 0, 0)
+    assert np.array_equal(y1, y2) and a == O.quantize_multiplier(float(np.float32(sx)) * float(np.float32(sw)) / float(np.float32(so)))

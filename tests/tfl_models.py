@@ -150,3 +150,117 @@ def mobilenet_like(rng, S=64, C=6):
     m.inputs = [x]
     m.outputs = [loc, both, mt, proto, cells]
     return m
+
+
+def mobilenetv2_yolact(rng, S=224, C=81, fpn=128, nproto=32):
+    """A full-size stand-in for the reference's data/FRC_model.tflite (absent; op census in
+    data/FRC_model_edgetpu.log:5-19, backbone per data/README.md:5-16): MobileNetV2 (width 1.0, 15
+    depthwise convs, 9 residual ADDs) + 3-level FPN with two extra stride-2 levels (PAD + VALID convs)
+    + protonet (one RESIZE_BILINEAR, one RELU) + a prediction head per level (TANH on the mask
+    coefficients), QUANTIZE / RESHAPE / CONCATENATION over the levels; five outputs, output 4 =
+    [1, (S/8)^2, C] class logits of the S/8 level (what src/yolact.rs:91 reads). Weights are random:
+    the graph is for executor parity against the numpy oracle and for timing, not for accuracy."""
+    m = Model()
+    sc = lambda: float(rng.uniform(0.02, 0.06))
+    zp = lambda: int(rng.integers(100, 150))
+
+    def conv(x, ci, co, k, stride, hw, act=3, padding=0, so=None, zo=None):
+        ws = 0.5 / (128.0 * np.sqrt(k * k * ci))          # keeps the accumulators in a sensible range
+        w = m.add(T(f"w{len(m.tensors)}", (co, k, k, ci), "u8", data=_q(rng, (co, k, k, ci), 64, 192), scale=float(ws * 8), zp=128))
+        b = m.add(T(f"b{len(m.tensors)}", (co,), "i32", data=rng.integers(-200, 200, co), scale=0.0002, zp=0))
+        ho = -(-hw // stride) if padding == 0 else (hw - k + stride) // stride
+        y = m.add(T(f"c{len(m.tensors)}", (1, ho, ho, co), "u8", scale=so or sc(), zp=zp() if zo is None else zo))
+        m.ops.append(Op("CONV_2D", [x, w, b], [y], padding=padding, stride_w=stride, stride_h=stride, act=act))
+        return y, ho
+
+    def dw(x, c, stride, hw):
+        w = m.add(T(f"dw{len(m.tensors)}", (1, 3, 3, c), "u8", data=_q(rng, (1, 3, 3, c), 64, 192), scale=0.01, zp=128))
+        b = m.add(T(f"db{len(m.tensors)}", (c,), "i32", data=rng.integers(-300, 300, c), scale=0.0005, zp=0))
+        ho = -(-hw // stride)
+        y = m.add(T(f"d{len(m.tensors)}", (1, ho, ho, c), "u8", scale=sc(), zp=zp()))
+        m.ops.append(Op("DEPTHWISE_CONV_2D", [x, w, b], [y], padding=0, stride_w=stride, stride_h=stride, act=3, depth_multiplier=1))
+        return y, ho
+
+    def add(a, b, shape):
+        y = m.add(T(f"a{len(m.tensors)}", shape, "u8", scale=sc(), zp=zp()))
+        m.ops.append(Op("ADD", [a, b], [y], act=0))
+        return y
+
+    def pad_valid_s2(x, c, co, hw):
+        """explicit PAD (0,1) + VALID 3x3 stride-2 conv: the converter's pattern for stride-2 SAME."""
+        xt = m.tensors[x]
+        pd = m.add(T(f"pads{len(m.tensors)}", (4, 2), "i32", data=[[0, 0], [0, 1], [0, 1], [0, 0]]))
+        p = m.add(T(f"padded{len(m.tensors)}", (1, hw + 1, hw + 1, c), "u8", scale=xt.scale, zp=xt.zp))
+        m.ops.append(Op("PAD", [x, pd], [p]))
+        return conv(p, c, co, 3, 2, hw + 1, act=1, padding=1)
+
+    x = m.add(T("input", (1, S, S, 3), "u8", scale=1 / 128, zp=128))
+    y, hw = conv(x, 3, 32, 3, 2, S)                                   # S/2
+    y, hw = dw(y, 32, 1, hw)
+    y, _ = conv(y, 32, 16, 1, 1, hw, act=0)
+    cin, feats = 16, {}
+    for t, c, n, s in ((6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 2, 2)):
+        for i in range(n):
+            stride = s if i == 0 else 1
+            e, _ = conv(y, cin, cin * t, 1, 1, hw)
+            d, hw2 = dw(e, cin * t, stride, hw)
+            p, _ = conv(d, cin * t, c, 1, 1, hw2, act=0)
+            y = add(y, p, (1, hw2, hw2, c)) if (stride == 1 and cin == c) else p
+            cin, hw = c, hw2
+        feats[hw] = (y, cin)                                          # last feature at each resolution
+    h8, h16, h32 = S // 8, S // 16, S // 32
+    # FPN: laterals, top-down (2 x RESIZE_BILINEAR + ADD), 3x3 output convs, two extra stride-2 levels
+    lat = {h: conv(feats[h][0], feats[h][1], fpn, 1, 1, h, act=0)[0] for h in (h8, h16, h32)}
+
+    def up(src, hs, hd):
+        st = m.tensors[src]
+        sz = m.add(T(f"size{len(m.tensors)}", (2,), "i32", data=[hd, hd]))
+        u = m.add(T(f"up{len(m.tensors)}", (1, hd, hd, st.shape[3]), "u8", scale=st.scale, zp=st.zp))
+        m.ops.append(Op("RESIZE_BILINEAR", [src, sz], [u], align_corners=False, half_pixel_centers=False))
+        return u
+    t16 = add(lat[h16], up(lat[h32], h32, h16), (1, h16, h16, fpn))
+    t8 = add(lat[h8], up(t16, h16, h8), (1, h8, h8, fpn))
+    levels = [(conv(t8, fpn, fpn, 3, 1, h8, act=1)[0], h8), (conv(t16, fpn, fpn, 3, 1, h16, act=1)[0], h16),
+              (conv(lat[h32], fpn, fpn, 3, 1, h32, act=1)[0], h32)]
+    p6, h64 = pad_valid_s2(levels[2][0], fpn, fpn, h32)
+    p7, h128 = pad_valid_s2(p6, fpn, fpn, h64)
+    levels += [(p6, h64), (p7, h128)]
+    # protonet on the S/8 level: 3 x conv3x3, x2 upsample, conv3x3, 1x1 -> prototypes, RELU
+    pr = levels[0][0]
+    for _ in range(3):
+        pr, _ = conv(pr, fpn, fpn, 3, 1, h8, act=1)
+    pr = up(pr, h8, 2 * h8)
+    pr, _ = conv(pr, fpn, fpn, 3, 1, 2 * h8, act=1)
+    pr, _ = conv(pr, fpn, nproto, 1, 1, 2 * h8, act=0)
+    proto = m.add(T("proto", (1, 2 * h8, 2 * h8, nproto), "u8", scale=0.05, zp=0))
+    m.ops.append(Op("RELU", [pr], [proto]))
+    # prediction head per level (weights unrolled per level, as a converter does with a shared head)
+    locs, confs, masks = [], [], []
+    for li, (f, h) in enumerate(levels):
+        t, _ = conv(f, fpn, fpn, 3, 1, h, act=1)
+        for name, co, dst, q_scale in (("loc", 12, locs, 1 / 64), ("conf", 3 * C, confs, 0.0625), ("mask", 3 * nproto, masks, 1 / 128)):
+            o, _ = conv(t, fpn, co, 3, 1, h, act=0)
+            if name == "mask":
+                th = m.add(T(f"tanh{li}", (1, h, h, co), "u8", scale=1 / 128, zp=128))
+                m.ops.append(Op("TANH", [o], [th]))
+                o = th
+            q = m.add(T(f"{name}_q{li}", (1, h, h, co), "u8", scale=q_scale, zp=128))
+            m.ops.append(Op("QUANTIZE", [o], [q]))
+            r = m.add(T(f"{name}_r{li}", (1, h * h * 3, co // 3), "u8", scale=q_scale, zp=128))
+            m.ops.append(Op("RESHAPE", [q], [r], new_shape=[1, h * h * 3, co // 3]))
+            dst.append(r)
+    npri = sum(h * h * 3 for _, h in levels)
+    outs = []
+    for name, parts, last in (("loc", locs, 4), ("conf", confs, C), ("mask", masks, nproto)):
+        o = m.add(T(f"{name}_all", (1, npri, last), "u8", scale=m.tensors[parts[0]].scale, zp=128))
+        m.ops.append(Op("CONCATENATION", parts, [o], axis=1))
+        outs.append(o)
+    # output 4: per-cell class logits of the S/8 level, [1, (S/8)^2, C] (src/yolact.rs:91, :108)
+    cl, _ = conv(levels[0][0], fpn, C, 1, 1, h8, act=0, so=0.0625, zo=128)
+    clq = m.add(T("cells_q", (1, h8, h8, C), "u8", scale=0.0078125, zp=128))
+    m.ops.append(Op("QUANTIZE", [cl], [clq]))
+    cells = m.add(T("cells", (1, h8 * h8, C), "u8", scale=0.0078125, zp=128))
+    m.ops.append(Op("RESHAPE", [clq], [cells], new_shape=[1, h8 * h8, C]))
+    m.inputs = [x]
+    m.outputs = [outs[0], outs[1], outs[2], proto, cells]
+    return m

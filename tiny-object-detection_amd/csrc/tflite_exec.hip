@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "tflite_model.h"
+#include <cstdlib>
 #include "yh_internal.h"
 
 using namespace yh;
@@ -209,6 +210,7 @@ struct yh_tfl {
     std::vector<void*> tens;
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
+    hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
     // classify scratch
     uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
     uint8_t* tiles_dev = nullptr;
@@ -395,7 +397,7 @@ int prepare(yh_tfl* h) {
     return YH_OK;
 }
 
-int run_plan(yh_tfl* h) {
+int enqueue_plan(yh_tfl* h) {
     hipStream_t s = h->stream;
     for (const Prepared& p : h->plan) {
         switch (p.kind) {
@@ -414,6 +416,26 @@ int run_plan(yh_tfl* h) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return h->fail(YH_EHIP, std::string("tflite plan launch: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
+// One invoke = one graph launch: a 136-op model is otherwise ~140 launches of microsecond kernels whose
+// host-side launch cost exceeds their run time. A/B switch: YH_TFL_GRAPH=0 launches eagerly.
+int run_plan(yh_tfl* h) {
+    static const int use_graph = getenv("YH_TFL_GRAPH") ? atoi(getenv("YH_TFL_GRAPH")) : 1;
+    if (!use_graph) return enqueue_plan(h);
+    if (!h->gexec) {
+        hipGraph_t g = nullptr;
+        TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_plan(h);
+        const hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { h->gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
+    }
+    TCHK(h, hipGraphLaunch(h->gexec, h->stream));
     return YH_OK;
 }
 
@@ -463,6 +485,7 @@ void yh_tfl_destroy(yh_tfl* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
     for (void* p : h->tens) if (p) hipFree(p);
     for (void* p : h->extra) hipFree(p);
     void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };
