@@ -48,6 +48,7 @@ struct ConvQ {
     const uint8_t *x, *w; const int* bias; uint8_t* y;
     int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, dm;
     int zx, zw, zo, mult, shift, lo, hi;
+    const int* wsum;   // [Co][kh*kw]: sum of the raw weight bytes of one tap (dot-product kernel), or nullptr
 };
 
 __global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
@@ -70,6 +71,75 @@ __global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
     p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
 }
 
+// Same arithmetic, four MACs per instruction: for Ci % 4 == 0 the sum over the valid taps of
+// (x - zx)(w - zw) is  sum(x w) - zw sum(x) - zx sum(w) + n zx zw  with the first two as
+// v_dot4_u32_u8 over raw bytes and sum(w) per (channel, tap) tabulated at load time — all exact in
+// int32 (|sum(x w)| <= 65025 * 9 * 1024 < 2^31 is checked when the plan is built). One lane = one
+// pixel x 8 output channels; the channel block is the grid's y index, so weight words are
+// wave-uniform and arrive through the scalar cache.
+// A workgroup = 64 pixels x 8 channels; with KS == 4 its four waves each take a quarter of the input
+// channels (the model's layers are small: 28 x 28 pixels x 128 channels is 13 x 16 workgroups, and
+// the serial chain per lane is what takes the time) and wave 0 adds the partial sums from LDS.
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(const ConvQ p) {
+    __shared__ unsigned part[KS > 1 ? (KS - 1) * 9 * 64 : 1];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int pix = blockIdx.x * 64 + lane, oc0 = blockIdx.y * 8;
+    const bool live = pix < p.Ho * p.Wo;
+    const int ox = live ? pix % p.Wo : 0, oy = live ? pix / p.Wo : 0, ci4 = p.Ci >> 2, ntaps = p.kh * p.kw;
+    const int c_lo = ks * (ci4 / KS), c_hi = c_lo + ci4 / KS;
+    const unsigned* w32 = (const unsigned*)p.w;
+    unsigned acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, sx = 0;
+    int ws[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, nv = 0;
+    for (int r = 0; r < p.kh; ++r) {
+        const int iy = oy * p.sh - p.ph + r * p.dh;
+        for (int s = 0; s < p.kw; ++s) {
+            const int ix = ox * p.sw - p.pw + s * p.dw, tap = r * p.kw + s;
+            if (!live || (unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+            const unsigned* xp = (const unsigned*)(p.x + ((size_t)iy * p.W + ix) * p.Ci);
+            for (int c = c_lo; c < c_hi; ++c) {
+                const unsigned xv = xp[c];
+                sx = __builtin_amdgcn_udot4(xv, 0x01010101u, sx, false);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int oc = oc0 + j < p.Co ? oc0 + j : p.Co - 1;   // wave-uniform; the clamped duplicates are not stored
+                    acc[j] = __builtin_amdgcn_udot4(xv, w32[((size_t)oc * ntaps + tap) * ci4 + c], acc[j], false);
+                }
+            }
+            if (ks == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ws[j] += p.wsum[(oc0 + j < p.Co ? oc0 + j : p.Co - 1) * ntaps + tap];
+                ++nv;
+            }
+        }
+    }
+    if (KS > 1) {
+        if (ks > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[((ks - 1) * 9 + j) * 64 + lane] = acc[j];
+            part[((ks - 1) * 9 + 8) * 64 + lane] = sx;
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += part[(k * 9 + j) * 64 + lane];
+            sx += part[(k * 9 + 8) * 64 + lane];
+        }
+    }
+    if (!live) return;
+    const int base = nv * p.Ci * p.zx * p.zw - p.zw * (int)sx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int oc = oc0 + j;
+        if (oc < p.Co) {
+            const int a = (int)acc[j] + base - p.zx * ws[j] + (p.bias ? p.bias[oc] : 0);
+            p.y[(size_t)pix * p.Co + oc] = (uint8_t)q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
@@ -86,6 +156,15 @@ __global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
     }
     acc += p.bias ? p.bias[oc] : 0;
     p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
+}
+
+// RESHAPE: a plain device copy as a kernel (a memcpy NODE in the captured plan crashed rocprofv3's
+// kernel tracing on graph replay; kernels are also what the profiler can attribute)
+__global__ __launch_bounds__(256) void tfl_copy_bytes(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n16 = n >> 4;
+    if (t < n16) ((uint4*)y)[t] = ((const uint4*)x)[t];
+    if (t < (n & 15)) y[(n16 << 4) + t] = x[(n16 << 4) + t];
 }
 
 struct AddQ { const uint8_t *a, *b; uint8_t* y; long long n; int za, zb, zo, m1, s1, m2, s2, mo, so, lo, hi; };
@@ -208,6 +287,7 @@ struct yh_tfl {
     std::vector<uint8_t> file;
     TflModel m;
     std::vector<void*> tens;
+    std::vector<char> alias;    // tens[i] shares another tensor's buffer (RESHAPE): not freed twice
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
     hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
@@ -229,6 +309,7 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 int prepare(yh_tfl* h) {
     TflModel& m = h->m;
     h->tens.assign(m.tensors.size(), nullptr);
+    h->alias.assign(m.tensors.size(), 0);
     for (size_t i = 0; i < m.tensors.size(); ++i) {
         const TflTensor& t = m.tensors[i];
         const size_t bytes = t.count() * t.elem();
@@ -270,6 +351,25 @@ int prepare(yh_tfl* h) {
                 quantize_multiplier((double)x.scale * (double)w.scale / (double)y.scale, &c.mult, &c.shift);
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
+                c.wsum = nullptr;
+                static const int use_dot = getenv("YH_TFL_DOT") ? atoi(getenv("YH_TFL_DOT")) : 1;   // A/B switch (tools/)
+                if (!dw && use_dot && c.Ci % 4 == 0 && w.data && (long long)c.kh * c.kw * c.Ci * 65025ll < (1ll << 31)) {
+                    // per (channel, tap) sums of the raw weight bytes for the dot-product kernel
+                    const int ntaps = c.kh * c.kw;
+                    std::vector<int> ws((size_t)c.Co * ntaps, 0);
+                    for (int o = 0; o < c.Co; ++o)
+                        for (int tp = 0; tp < ntaps; ++tp) {
+                            int sum = 0;
+                            const uint8_t* wp = w.data + ((size_t)o * ntaps + tp) * c.Ci;
+                            for (int ch = 0; ch < c.Ci; ++ch) sum += wp[ch];
+                            ws[(size_t)o * ntaps + tp] = sum;
+                        }
+                    void* d = nullptr;
+                    if (hipMalloc(&d, ws.size() * 4) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc weight sums");
+                    h->extra.push_back(d);
+                    if (hipMemcpy(d, ws.data(), ws.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return h->fail(YH_EHIP, "weight sums upload");
+                    c.wsum = (const int*)d;
+                }
                 break;
             }
             case TFL_ADD: {
@@ -383,6 +483,15 @@ int prepare(yh_tfl* h) {
             }
             case TFL_RESHAPE: {
                 if (!need(!op.in.empty() && T(op.in[0]).count() * T(op.in[0]).elem() == T(op.out[0]).count() * T(op.out[0]).elem(), "reshape: size mismatch" + at)) return YH_EINVAL;
+                // RESHAPE moves no bytes: every tensor is written once by its producer, so the output can
+                // share the input's buffer (ops are in topological order: its consumers are prepared later
+                // and pick the shared pointer up). Only a reshape of a constant keeps its own copy.
+                if (!T(op.in[0]).data && !T(op.out[0]).data) {
+                    hipFree(h->tens[op.out[0]]);
+                    h->tens[op.out[0]] = h->tens[op.in[0]];
+                    h->alias[op.out[0]] = 1;
+                    continue;
+                }
                 pr.kind = P_COPY; pr.src = h->tens[op.in[0]]; pr.dst = h->tens[op.out[0]]; pr.n = (long long)(T(op.out[0]).count() * T(op.out[0]).elem());
                 break;
             }
@@ -401,7 +510,14 @@ int enqueue_plan(yh_tfl* h) {
     hipStream_t s = h->stream;
     for (const Prepared& p : h->plan) {
         switch (p.kind) {
-            case P_CONV: hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv); break;
+            case P_CONV:
+                if (p.conv.wsum) {
+                    const dim3 grid((unsigned)(((long long)p.conv.Ho * p.conv.Wo + 63) / 64), (unsigned)((p.conv.Co + 7) / 8));
+                    if (p.conv.Ci % 16 == 0) hipLaunchKernelGGL(tfl_conv_u8_dot<4>, grid, dim3(256), 0, s, p.conv);
+                    else hipLaunchKernelGGL(tfl_conv_u8_dot<1>, grid, dim3(64), 0, s, p.conv);
+                }
+                else hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv);
+                break;
             case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv); break;
             case P_ADD: hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(p.add.n)), dim3(256), 0, s, p.add); break;
             case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
@@ -411,7 +527,7 @@ int enqueue_plan(yh_tfl* h) {
             case P_PAD: hipLaunchKernelGGL(tfl_pad_u8, dim3(nblk((long long)p.pad.od[0] * p.pad.od[1] * p.pad.od[2] * p.pad.od[3])), dim3(256), 0, s, p.pad); break;
             case P_RESIZE: hipLaunchKernelGGL(tfl_resize_bilinear_u8, dim3(nblk((long long)p.rs.Ho * p.rs.Wo * p.rs.C)), dim3(256), 0, s, p.rs); break;
             case P_CONCAT: for (const CatQ& c : p.cat) hipLaunchKernelGGL(tfl_concat_part, dim3(nblk(c.outer * c.inner * c.esz)), dim3(256), 0, s, c); break;
-            case P_COPY: if (hipMemcpyAsync(p.dst, p.src, (size_t)p.n, hipMemcpyDeviceToDevice, s) != hipSuccess) return h->fail(YH_EHIP, "reshape copy failed"); break;
+            case P_COPY: hipLaunchKernelGGL(tfl_copy_bytes, dim3(nblk((p.n >> 4) + 16)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n); break;
         }
     }
     hipError_t e = hipGetLastError();
@@ -419,10 +535,12 @@ int enqueue_plan(yh_tfl* h) {
     return YH_OK;
 }
 
-// One invoke = one graph launch: a 136-op model is otherwise ~140 launches of microsecond kernels whose
-// host-side launch cost exceeds their run time. A/B switch: YH_TFL_GRAPH=0 launches eagerly.
+// Optional (YH_TFL_GRAPH=1): one invoke = one graph launch. It measures 5 % faster per invoke on the
+// 136-op model (1.11 vs 1.17 ms; the step is bound by kernel time, not by launches) and is off by
+// default because rocprofv3 --kernel-trace crashed inside hipGraphLaunch after ~110 replays of this
+// 137-kernel graph (the YOLACT engine's graphs replay under the profiler without trouble).
 int run_plan(yh_tfl* h) {
-    static const int use_graph = getenv("YH_TFL_GRAPH") ? atoi(getenv("YH_TFL_GRAPH")) : 1;
+    static const int use_graph = getenv("YH_TFL_GRAPH") ? atoi(getenv("YH_TFL_GRAPH")) : 0;
     if (!use_graph) return enqueue_plan(h);
     if (!h->gexec) {
         hipGraph_t g = nullptr;
@@ -486,7 +604,7 @@ void yh_tfl_destroy(yh_tfl* h) {
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
-    for (void* p : h->tens) if (p) hipFree(p);
+    for (size_t i = 0; i < h->tens.size(); ++i) if (h->tens[i] && !(i < h->alias.size() && h->alias[i])) hipFree(h->tens[i]);
     for (void* p : h->extra) hipFree(p);
     void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };
     for (void* p : scratch) if (p) hipFree(p);
