@@ -69,3 +69,24 @@ def test_roofline_helper_picks_dominant_kernel():
     r = bench.roofline_of(prof)
     assert r["kernel"] == "conv_a" and r["bound"] == "mfma" and r["launches"] == 2
     assert abs(r["achieved"] - 2000.0) < 1e-6 and abs(r["frac"] - 0.8) < 1e-9
+
+
+def test_accuracy_helper_matches_by_class_and_prior():
+    """bench.accuracy_vs_oracle (the engine-vs-oracle report in the bench line): detections are matched
+    by (class, prior); the IoU is pooled over matched pairs only."""
+    import bench
+    m = np.zeros((2, 4, 4), np.uint8); m[0, :2] = 1; m[1, 1:3, 1:3] = 1
+    eng = ([dict(class_id=3, prior=7), dict(class_id=5, prior=9)], m)
+    om = m.copy(); om[0, 2, 0] = 1                                     # one extra pixel in the first mask
+    orc = ([dict(class_id=3, prior=7), dict(class_id=5, prior=9), dict(class_id=1, prior=2)], np.concatenate([om, np.ones((1, 4, 4), np.uint8)]))
+    r = bench.accuracy_vs_oracle(eng, orc)
+    assert r["oracle_dets"] == 3 and r["engine_dets"] == 2 and r["matched_class_and_prior"] == 2
+    assert abs(r["mask_iou_matched"] - (8 + 4) / (9 + 4)) < 1e-4
+    assert bench.accuracy_vs_oracle(([], m[:0]), ([], m[:0]))["mask_iou_matched"] is None
+
+
+def test_measured_traffic_reads_the_committed_pmc_file():
+    import bench
+    t, src = bench.measured_traffic("conv_igemm_f16<256,256,2,4,0,2,mfma16>", 64)
+    assert src and src.startswith("profiles/") and t > 1e8
+    assert bench.measured_traffic("no_such_kernel", 64) == (None, None)
