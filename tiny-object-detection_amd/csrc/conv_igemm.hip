@@ -914,12 +914,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
                  case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_X3: case TILE_ROWPATCH_256: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -939,6 +939,8 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
         case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
+        case TILE_64x64_S3: return "conv_igemm_f16<64,64,2,2,0,3>";
+        case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
     }
     return "?";
 }
@@ -958,6 +960,8 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
         if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);
         else if (tile == TILE_128x128_S4) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1, true>), gk, dim3(256), 0, stream, p);
+        else if (tile == TILE_64x64_S3) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);
+        else if (tile == TILE_64x64_S4) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1, true>), gk, dim3(256), 0, stream, p);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -971,6 +975,8 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_64x64_S4: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;

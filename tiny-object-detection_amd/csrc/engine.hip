@@ -504,6 +504,12 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
     const ConvTile t = pick_tile_base(pn, M, stride, pad);
     static const int s4 = getenv("YH_S4") ? atoi(getenv("YH_S4")) : 0;   // A/B switch (tools/): ring of four for the latency-bound tile
     if (s4 && t == TILE_128x128_S3) return TILE_128x128_S4;
+    // Latency-bound launches with few 128 x 128 tiles: 64 x 64 tiles put four times as many workgroups on
+    // the idle CUs and a K step costs a wave 4 MFMAs instead of 16 (A/B switch YH_T64; 0 = off)
+    static const int t64 = getenv("YH_T64") ? atoi(getenv("YH_T64")) : 2;
+    static const int t64_max = getenv("YH_T64_MAXB") ? atoi(getenv("YH_T64_MAXB")) : 256;
+    static const int t64_s4 = getenv("YH_T64_S4") ? atoi(getenv("YH_T64_S4")) : 0;
+    if (t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= t64_max) return t64_s4 ? TILE_64x64_S4 : TILE_64x64_S3;
     // 128 x 256: the 2-stage 16x16x32 form measures ~5 % faster than the 3-stage 32x32x16 ring on stride-1
     // layers (0.112 vs 0.118 ms on the 69 x 69 3x3 convs at batch 64) and slower on the stride-2 one
     static const int t128m16 = getenv("YH_128X256_M16") ? atoi(getenv("YH_128X256_M16")) : 1;   // A/B switch (tools/)
@@ -655,10 +661,15 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
     static const int splitk_min = getenv("YH_SPLITK_MINSTEPS") ? atoi(getenv("YH_SPLITK_MINSTEPS")) : 12;   // A/B switch (tools/)
-    if ((tile == TILE_128x128_S3 || tile == TILE_128x128_S4) && p.ksteps >= splitk_min) {
+    static const int t64_mode = getenv("YH_T64") ? atoi(getenv("YH_T64")) : 2;
+    static const int t64_min = getenv("YH_T64_MINSTEPS") ? atoi(getenv("YH_T64_MINSTEPS")) : 24;
+    const bool ring128 = tile == TILE_128x128_S3 || tile == TILE_128x128_S4;
+    const bool ring64 = (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && t64_mode >= 2;
+    if ((ring128 && p.ksteps >= splitk_min) || (ring64 && p.ksteps >= t64_min)) {
         // few tiles, long K: split K so that about one workgroup per CU streams the weights
-        const long long tiles = (long long)((p.M + 127) / 128) * p.n_ch_tiles;
-        int sl = (int)(256 / tiles);
+        const int tm = conv_tile_m(tile);
+        const long long tiles = (long long)((p.M + tm - 1) / tm) * p.n_ch_tiles;
+        int sl = (int)((ring64 ? 512 : 256) / tiles);
         if (sl > p.ksteps / 4) sl = p.ksteps / 4;  // at least 4 steps per slice
         if (sl > 16) sl = 16;
         const size_t need = (size_t)sl * p.M * pn.coutPad * 4;
