@@ -127,12 +127,26 @@ def pcie_inclusive(eng, host_frames, steps=5):
     """Wall-clock frames/s when the boundary is handed HOST buffers (yh_set_input_u8: pageable
     host -> device copy of the uint8 frames, then the step, then a sync). Never the headline value."""
     n = host_frames.shape[0]
+    steps = steps if n > 4 else 50
     eng.set_input(host_frames); eng.evaluate(); eng.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.set_input(host_frames); eng.evaluate()
     eng.sync()
     return round(n * steps / (time.perf_counter() - t0), 2)
+
+
+def host_to_detections_latency(eng, host_frames, reps=100):
+    """Wall-clock latency of one synchronous request: host frames in (yh_set_input_u8), step, sync,
+    detections of frame 0 read back to the host (boxes, scores, classes; no masks)."""
+    import numpy as np
+    t = []
+    for _ in range(reps + 5):
+        t0 = time.perf_counter()
+        eng.set_input(host_frames); eng.evaluate(); eng.sync(); eng.detections(0, want_masks=False)
+        t.append(time.perf_counter() - t0)
+    t = np.array(t[5:]) * 1e3
+    return dict(n=reps, median_ms=round(float(np.median(t)), 4), p99_ms=round(float(np.percentile(t, 99)), 4))
 
 
 def accuracy_vs_oracle(eng_out, orc_out):
@@ -219,6 +233,8 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
         aux["host_frame"] = host[:1]
         aux["latency"] = latency_stats(eng)
         aux["pcie_inclusive_fps"] = pcie_inclusive(eng, host)
+        if batch == 1:
+            aux["host_to_detections_latency"] = host_to_detections_latency(eng, host)
         eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
         aux["dets_frame0"] = eng.detections(0, want_masks=True)
     if dist is not None:
@@ -284,7 +300,8 @@ def main():
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
-                                   latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"])
+                                   latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"],
+                                   host_to_detections_latency=aux1.get("host_to_detections_latency"))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -134,6 +134,10 @@ struct yh_engine {
 
     bool weights_loaded = false;
     int cur_n = 0;
+    static constexpr size_t kStageBytes = 4u << 20;   // pinned staging for small host inputs
+    uint8_t* stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_ev[2] = { nullptr, nullptr };
+    int stage_idx = 0;
     int last_conv_launches = 0;   // yh_debug_last_conv_launches
     bool stem_fused = false;
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
@@ -996,6 +1000,7 @@ void yh_destroy(yh_engine* h) {
     if (h->diverged_dev) hipFree(h->diverged_dev);
     for (hipEvent_t ev : h->op_done) if (ev) hipEventDestroy(ev);
     for (int l = 1; l < yh_engine::kLanes; ++l) if (h->lanes[l]) { hipStreamSynchronize(h->lanes[l]); hipStreamDestroy(h->lanes[l]); }
+    for (int k = 0; k < 2; ++k) { if (h->stage_ev[k]) hipEventDestroy(h->stage_ev[k]); if (h->stage[k]) hipHostFree(h->stage[k]); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1061,7 +1066,27 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     if (!h || !src) return YH_EINVAL;
     if (n < 1 || n > h->cfg.max_batch) return h->fail(YH_EINVAL, "n_frames out of range");
     HIPCHK(h, hipSetDevice(h->dev));
-    HIPCHK(h, hipMemcpyAsync(h->in_u8, src, (size_t)n * h->S * h->S * 3, kind, h->stream));
+    const size_t bytes = (size_t)n * h->S * h->S * 3;
+    // Small host inputs (a camera frame or two) go through a pinned double buffer: an async copy from
+    // PAGEABLE memory first drains the stream, so frame k+1's copy could not start before frame k's
+    // step had finished (0.49 of the resident rate at batch 1). The caller's buffer is free again on
+    // return either way. Large batches keep the runtime's own pageable path, which pipelines its chunks
+    // and beats a single-threaded memcpy into staging.
+    if (kind == hipMemcpyHostToDevice && bytes <= yh_engine::kStageBytes) {
+        const int k = h->stage_idx ^= 1;
+        if (!h->stage[k]) {
+            HIPCHK(h, hipHostMalloc((void**)&h->stage[k], yh_engine::kStageBytes, hipHostMallocDefault));
+            HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+        } else {
+            HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this buffer has finished
+        }
+        memcpy(h->stage[k], src, bytes);
+        HIPCHK(h, hipMemcpyAsync(h->in_u8, h->stage[k], bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipEventRecord(h->stage_ev[k], h->stream));
+        h->cur_n = n;
+        return YH_OK;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->in_u8, src, bytes, kind, h->stream));
     h->cur_n = n;
     return YH_OK;
 }
