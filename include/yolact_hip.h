@@ -244,6 +244,11 @@ int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, i
 /* 3x3 stride-2 pad-1 max pool of an NHWC f16 tensor. */
 int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww,
                            int32_t c, uint16_t* y);
+/* The shared prediction head's form of the convolution: x[n][cells][cin] holds nlev square pyramid
+ * levels (edge lengths level_sizes[]) end to end per image; a k x k stride-1 'same' conv runs over all
+ * of them in one launch, every tap staying inside its row's own level. y[n][cells][cout]. */
+int yh_op_conv2d_levels_f16(yh_engine* h, const uint16_t* x, int32_t n, const int32_t* level_sizes, int32_t nlev, int32_t cin,
+                            const uint16_t* w, const float* bias, int32_t cout, int32_t k, int32_t act, uint16_t* y);
 /* The fused stem (conv 7x7 stride 2 pad 3, 3 -> 64, bias, ReLU; then max pool 3x3 stride 2 pad 1) on
  * x[n][S][S][3] f16 bits with w[64][7][7][3]; S even. Writes pool_out[n][PO][PO][64] and, if not NULL,
  * stem_out[n][SO][SO][64] (the pre-pool tensor, a test hook). */

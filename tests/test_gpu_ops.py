@@ -190,6 +190,61 @@ def test_stem_pool_fused_vs_oracle_random(eng, oracle):
     assert np.array_equal(pool, oracle.maxpool3x3s2(stem))       # the pool of ITS stem is exact
 
 
+# ConvTile ids (csrc/yh_internal.h): the variants a head conv can be launched on
+_TILES = {"128x128": 0, "128x256": 5, "128x128_S3": 7, "256x256_M16": 8, "128x128_M16": 12, "128x128_S3_M16": 13, "128x256_M16": 15, "64x64_S3": 16}
+
+
+def _forced(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k)
+            else: os.environ[k] = v
+
+
+@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _TILES] + [("128x128_S3", 3), ("64x64_S3", 4)])
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
+    """The shared head's multi-level form (one launch over pyramid levels laid end to end) on every tile
+    variant it can be launched on, split-K included: each level must equal the oracle's convolution of
+    that level alone, bit for bit - in particular no tap may reach into the neighbouring level's cells
+    (level edges 9, 5, 3, 1: every level boundary falls inside a tile)."""
+    rng = np.random.default_rng(k)
+    sizes, n, cin, cout = [9, 5, 3, 1], 3, 128, 256
+    cells = sum(s * s for s in sizes)
+    x = rng.integers(-3, 4, (n, cells, cin)).astype(np.float32)
+    wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    env = {"YH_OP_TILE": _TILES[tile]}
+    if kslices: env["YH_OP_KSLICES"] = kslices
+    y = _forced(env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
+    off = 0
+    for s_ in sizes:
+        xl = x[:, off:off + s_ * s_].reshape(n, s_, s_, cin)
+        yo = oracle.conv2d(f16(xl), f16(wt), b, 1, k // 2, None, 1, f16=True).reshape(n, s_ * s_, cout)
+        assert np.array_equal(y[:, off:off + s_ * s_], yo), (tile, s_)
+        off += s_ * s_
+
+
+@pytest.mark.parametrize("tile,kslices", [("128x128_S3", 0), ("64x64_S3", 0), ("128x128_S3", 2), ("64x64_S3", 5), ("128x128_M16", 0), ("128x128_S3_M16", 0)])
+def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
+    """The latency-bound tile variants the engine picks at small batch (3-stage 128x128 and 64x64 rings,
+    their split-K forms, the 16x16x32 tail tiles), forced through the op entry: ragged M, residual, ReLU."""
+    rng = np.random.default_rng(3)
+    x = rng.integers(-3, 4, (2, 13, 11, 128)).astype(np.float32)
+    wt = rng.integers(-2, 3, (192, 3, 3, 128)).astype(np.float32)
+    b = rng.integers(-4, 5, 192).astype(np.float32)
+    r = rng.integers(-5, 6, (2, 13, 11, 192)).astype(np.float32)
+    env = {"YH_OP_TILE": _TILES[tile]}
+    if kslices: env["YH_OP_KSLICES"] = kslices
+    y = _forced(env, lambda: eng.op_conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1))
+    assert np.array_equal(y, oracle.conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1, f16=True))
+
+
 @pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))

@@ -51,8 +51,9 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 //      lane); 16: v_mfma_f32_16x16x32_f16 (K = 32, 4 accumulators per lane: lane l holds output
 //      pixel l & 15 and channels 4 (l >> 4) .. + 3). Same FLOPs per cycle; on real data the chip
 //      holds a higher clock on the 16x16x32 shape (guide: DVFS give-back item 7).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32>
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
+    static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
     constexpr int TC = WTC / MT, TMT = WTM / MT;   // MFMA tiles per wave
@@ -97,11 +98,25 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // SOURCE side: it fetches logical chunk lc = (tid & 7) ^ ((row >> 1) & 7).
     const int lc = chunk ^ ((rb >> 1) & 7);
     int xbase[XL], xih[XL], xiw[XL];
+    int xH[ML ? XL : 1], xW[ML ? XL : 1];   // ML: the row's own level geometry (stride 1 only)
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
         const int m = m_tile * TM + rb + RSTEP * i;
+        if (ML) { xH[i] = 1; xW[i] = 1; }
         if (m < p.M) {
             const int n = m / PQ, rem = m - n * PQ;
+            if (ML) {
+                int st = 0, hh = p.lev_h[0], ww = p.lev_w[0];
+#pragma unroll
+                for (int L = 1; L < 5; ++L)
+                    if (L < p.nlev && rem >= p.lev_start[L]) { st = p.lev_start[L]; hh = p.lev_h[L]; ww = p.lev_w[L]; }
+                const int local = rem - st, op = local / ww, oq = local - op * ww;
+                xih[i] = op - p.pad;
+                xiw[i] = oq - p.pad;
+                xH[i] = hh; xW[i] = ww;
+                xbase[i] = (int)(n * p.x_img_stride) + (st + xih[i] * ww + xiw[i]) * p.C + lc * 8;
+                continue;
+            }
             const int op = rem / p.Q, oq = rem - op * p.Q;
             xih[i] = op * p.stride - p.pad;
             xiw[i] = oq * p.stride - p.pad;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // One tile's DMA is NDMA instructions per thread (WL weight pieces, then XL activation pieces).
     // tile_begin fixes the tile's K position, tile_part issues piece d, tile_end advances K.
     constexpr int NDMA = XL + WL;
-    int t_r = 0, t_s = 0, t_off = 0, t_wk = 0;
+    int t_r = 0, t_s = 0, t_off = 0, t_wk = 0, kc_cur = 0;
     auto tile_begin = [&]() {
         if (SMALLC) {
             const int2 tap = p.rs_table[kt_load * 8 + lc];
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             t_off = (t_r * p.W + t_s) * p.C;   // chunk = 16 bytes starting at tap (r,s): 8/C pixels
             t_wk = kt_load * 64;
         } else {
-            t_r = kr; t_s = ks;
+            t_r = kr; t_s = ks; kc_cur = kc;
             t_off = (kr * p.W + ks) * p.C + kc;
             t_wk = (kr * p.S + ks) * p.C + kc;   // K index of this step in the [(r,s,c)] weight panel
         }
@@ -153,9 +168,11 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                                                      (int)(wbase + (unsigned)((RSTEP * d) * p.ldw + t_wk) * 2u), 0, 0, 0);
         } else {
             const int i = d - WL;
-            const bool ok = (unsigned)(xih[i] + t_r) < (unsigned)p.H && (unsigned)(xiw[i] + t_s) < (unsigned)p.W;
+            const bool ok = ML ? ((unsigned)(xih[i] + t_r) < (unsigned)xH[i] && (unsigned)(xiw[i] + t_s) < (unsigned)xW[i])
+                               : ((unsigned)(xih[i] + t_r) < (unsigned)p.H && (unsigned)(xiw[i] + t_s) < (unsigned)p.W);
             // padded taps read the 16-byte zero block that ends every activation allocation
-            const unsigned voff = ok ? (unsigned)(xbase[i] + t_off) * 2u : p.x_zero_off;
+            const int toff = ML ? (t_r * xW[i] + t_s) * p.C + kc_cur : t_off;
+            const unsigned voff = ok ? (unsigned)(xbase[i] + toff) * 2u : p.x_zero_off;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstw + TCH * 128 + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
         }
     };
@@ -956,6 +973,29 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm - p.m_tile0;
     if (n_m_tiles < 1) return hipErrorInvalidValue;
+    if (p.nlev > 0) {   // multi-level input (the shared prediction head over the whole pyramid): the tiles a head conv can get
+        if (p.stride != 1 || p.nlev > 5) return hipErrorInvalidValue;
+        if (p.k_slices > 1) {
+            const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
+            if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true, 32, true>), gk, dim3(256), 0, stream, p);
+            else if (tile == TILE_64x64_S3) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, true, 32, true>), gk, dim3(256), 0, stream, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
+        switch (tile) {
+            case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, true>), grid, dim3(512), 0, stream, p); break;
+            case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16, true>), grid, dim3(512), 0, stream, p); break;
+            case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1, false, 32, true>), grid, dim3(512), 0, stream, p); break;
+            case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (p.k_slices > 1) {   // split-K main kernel; launch_splitk_reduce finishes it
         const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
         if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);

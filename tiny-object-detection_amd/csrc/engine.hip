@@ -58,6 +58,7 @@ struct Op {
     int panel = -1;
     int stride = 1, pad = 0, act = 0, tanh_from = INT_MAX;
     int P = 0, Q = 0;      // output spatial
+    int nlev = 0, lev_start[5] = {0, 0, 0, 0, 0}, lev_h[5] = {0, 0, 0, 0, 0}, lev_w[5] = {0, 0, 0, 0, 0};   // multi-level input (ConvParams)
     double flops_per_img = 0, bytes_per_img = 0, bytes_fixed = 0;
     int lane = 0;              // stream the op runs on when branch concurrency is on
     std::vector<int> deps;     // producer ops on OTHER lanes (RAW through in / res)
@@ -393,10 +394,34 @@ int build_graph_spec(yh_engine* h) {
     const int out_panel = add_panel(h, { ci + 1, ci + 2, ci + 3 });
     ci += 4;
     const int ci_end = ci;
+    // The head's weights are shared by the five levels, whose cells lie end to end in the pyramid
+    // buffers: ONE launch per head conv covers all of them (multi-level input: every tap stays inside its
+    // row's own level), instead of five launches of which three have a handful of tiles. YH_HEADMERGE=0
+    // restores one launch per level.
+    static const int headmerge = getenv("YH_HEADMERGE") ? atoi(getenv("YH_HEADMERGE")) : 1;
+    auto merged = [&](const char* name, int panel, const Buf& in, const Buf& out, int act) {
+        Buf bi = in, bo = out;
+        bi.h = bo.h = h->cells; bi.w = bo.w = 1;
+        Op o = conv_op(h, name, panel, bi, bo, 1, 1, act, nullptr);
+        o.P = h->cells; o.Q = 1;
+        o.nlev = 5;
+        for (int l = 0; l < 5; ++l) { o.lev_start[l] = h->lvl_off[l]; o.lev_h[l] = o.lev_w[l] = h->lvl[l]; }
+        const Panel& pn = h->panels[panel];
+        const double K = (double)pn.k * pn.k * h->convs[pn.src[0]].cin;
+        o.flops_per_img = 2.0 * h->cells * pn.cout * K;
+        o.bytes_per_img = 2.0 * ((double)h->cells * h->convs[pn.src[0]].cin + (double)h->cells * pn.cout);
+        return o;
+    };
+    for (int l = 0; l < 5; ++l) { snprintf(nm, sizeof nm, "head_t%d", l); h->named[nm] = level(h->pyr_t, l); }
+    if (headmerge) {
+        h->ops.push_back(merged("head_t", trunk_panel, h->pyr, h->pyr_t, 1));
+        Op o = merged("head_out", out_panel, h->pyr_t, h->heads, 0);
+        o.tanh_from = 12 + 3 * h->C;
+        h->ops.push_back(o);
+    } else
     for (int l = 0; l < 5; ++l) {
         snprintf(nm, sizeof nm, "head_t%d", l);
         h->ops.push_back(conv_op(h, nm, trunk_panel, level(h->pyr, l), level(h->pyr_t, l), 1, 1, 1, nullptr));
-        h->named[nm] = level(h->pyr_t, l);
         snprintf(nm, sizeof nm, "head_out%d", l);
         Op o = conv_op(h, nm, out_panel, level(h->pyr_t, l), level(h->heads, l), 1, 1, 0, nullptr);
         o.tanh_from = 12 + 3 * h->C;
@@ -431,7 +456,7 @@ int build_graph_spec(yh_engine* h) {
         if (ends("_d") || n == "p5" || n == "p6" || n == "p7" || n == "head_t2" || n == "head_out2" || n == "head_t3" ||
             n == "head_out3" || n == "head_t4" || n == "head_out4") o.lane = 1;
         else if (n == "p4" || n == "head_t1" || n == "head_out1") o.lane = 2;
-        else if (n == "head_t0" || n == "head_out0") o.lane = 3;
+        else if (n == "head_t0" || n == "head_out0" || n == "head_t" || n == "head_out") o.lane = 3;
         else o.lane = 0;
     }
     for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -501,19 +526,20 @@ int alloc_tail(yh_engine* h) {
 // ------------------------------------------------------------------------------------------------
 // The panel fixes the widest channel tile (coutPad); per launch, fall back to the 4-wave
 // 128 x 128 tile (2 workgroups per CU) when the big tile would leave most of the 256 CUs idle.
-ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad);
-ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
+ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml);
+// ml: the op has a multi-level input (only the tiles launch_conv instantiates for it may be chosen)
+ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0, bool ml = false) {
     // A/B switch (tools/): the 16x16x32 forms of the 128 x 128 tiles everywhere
     static const int small16 = getenv("YH_SMALL16") ? atoi(getenv("YH_SMALL16")) : 0;
-    const ConvTile t = pick_tile_base(pn, M, stride, pad);
+    const ConvTile t = pick_tile_base(pn, M, stride, pad, ml);
     static const int s4 = getenv("YH_S4") ? atoi(getenv("YH_S4")) : 0;   // A/B switch (tools/): ring of four for the latency-bound tile
-    if (s4 && t == TILE_128x128_S3) return TILE_128x128_S4;
+    if (s4 && !ml && t == TILE_128x128_S3) return TILE_128x128_S4;
     // Latency-bound launches with few 128 x 128 tiles: 64 x 64 tiles put four times as many workgroups on
     // the idle CUs and a K step costs a wave 4 MFMAs instead of 16 (A/B switch YH_T64; 0 = off)
     static const int t64 = getenv("YH_T64") ? atoi(getenv("YH_T64")) : 2;
     static const int t64_max = getenv("YH_T64_MAXB") ? atoi(getenv("YH_T64_MAXB")) : 256;
     static const int t64_s4 = getenv("YH_T64_S4") ? atoi(getenv("YH_T64_S4")) : 0;
-    if (t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= t64_max) return t64_s4 ? TILE_64x64_S4 : TILE_64x64_S3;
+    if (t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= t64_max) return t64_s4 && !ml ? TILE_64x64_S4 : TILE_64x64_S3;
     // 128 x 256: the 2-stage 16x16x32 form measures ~5 % faster than the 3-stage 32x32x16 ring on stride-1
     // layers (0.112 vs 0.118 ms on the 69 x 69 3x3 convs at batch 64) and slower on the stride-2 one
     static const int t128m16 = getenv("YH_128X256_M16") ? atoi(getenv("YH_128X256_M16")) : 1;   // A/B switch (tools/)
@@ -522,11 +548,11 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0) {
     if (small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
     return t;
 }
-ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad) {
+ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml) {
     // stride-1 k x k (k odd, 'same' padding) layers: the row-patch kernel shares one activation patch
     // between the k taps of a kernel row (conv_igemm.hip). A/B switch: YH_ROWPATCH=0 disables.
     static const int rowpatch = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;   // measured slower: off
-    if (rowpatch && stride == 1 && pn.k == 3 && pad == 1 && pn.cin_store % 64 == 0) {
+    if (rowpatch && !ml && stride == 1 && pn.k == 3 && pad == 1 && pn.cin_store % 64 == 0) {
         if (pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) >= 192) return TILE_ROWPATCH_256;
         if (rowpatch >= 2 && (pn.tile == TILE_128x256 || pn.tile == TILE_256x256 || pn.tile == TILE_128x128) &&
             (long long)((M + 255) / 256) * (pn.coutPad / 128) >= 192) return TILE_ROWPATCH_128;
@@ -547,8 +573,8 @@ ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad) {
     }
     static const int mfma16 = getenv("YH_MFMA16") ? atoi(getenv("YH_MFMA16")) : 1;   // A/B switch (tools/): default 16x16x32
     static const int x3 = getenv("YH_X3") ? atoi(getenv("YH_X3")) : 0;   // A/B switch (tools/): X3W2 ring
-    if (pn.tile == TILE_256x256 && x3) return TILE_256x256_X3;
-    if (pn.tile == TILE_256x256 && mfma16) return TILE_256x256_M16;
+    if (pn.tile == TILE_256x256 && x3 && !ml) return TILE_256x256_X3;
+    if (pn.tile == TILE_256x256 && (mfma16 || ml)) return TILE_256x256_M16;
     return pn.tile;
 }
 
@@ -656,12 +682,14 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     const long long pq = (long long)o.P * o.Q;
     p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
     p.act = o.act; p.tanh_from = o.tanh_from;
+    p.nlev = o.nlev;
+    for (int l = 0; l < 5; ++l) { p.lev_start[l] = o.lev_start[l]; p.lev_h[l] = o.lev_h[l]; p.lev_w[l] = o.lev_w[l]; }
     // timing-only ablation (tools/): zero-record descriptors drop every load through them
     static const int ablate = getenv("YH_ABLATE") ? atoi(getenv("YH_ABLATE")) : 0;
 
     if (ablate & 1) { p.x_bytes = 0; }
     if (ablate & 2) { p.w_bytes = 0; }
-    const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad);
+    const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0);
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
     static const int splitk_min = getenv("YH_SPLITK_MINSTEPS") ? atoi(getenv("YH_SPLITK_MINSTEPS")) : 12;   // A/B switch (tools/)
@@ -701,7 +729,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
             const Panel& pn = h->panels[o.panel];
-            e = launch_conv_planned(p, pick_tile(pn, p.M, o.stride, o.pad), pn.coutPad, h->stream);
+            e = launch_conv_planned(p, pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, h->stream);
             break;
         }
         case OP_POOL:
@@ -1350,7 +1378,7 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         if (rc) return rc;
         const Panel& pn = h->panels[o.panel];
         KLaunch k[2];
-        const int nk = plan_conv(p, pick_tile(pn, p.M, o.stride, o.pad), pn.coutPad, k);
+        const int nk = plan_conv(p, pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, k);
         for (int j = 0; j < nk; ++j) { ProfEntry e{}; e.op = i; e.stage = -1; e.k = k[j]; e.is_conv = true; out->push_back(e); }
     }
     if (with_tail)
@@ -1430,15 +1458,16 @@ int yh_time_steps(yh_engine* h, int32_t with_tail, int32_t steps, float* ms_tota
 }
 
 // ---- single-op entry points (tests) ------------------------------------------------------------
-int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint16_t* w,
-                     const float* bias, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
-                     const uint16_t* residual, int32_t act, uint16_t* y) {
+static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint16_t* w,
+                          const float* bias, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                          const uint16_t* residual, int32_t act, uint16_t* y, const int32_t* level_sizes, int32_t nlev) {
     if (!h || !x || !w || !bias || !y) return YH_EINVAL;
     if (kh != kw || kh < 1 || stride < 1 || n < 1 || (cin != 3 && cin % 64 != 0) || (act < 0 || act > 2))
         return h->fail(YH_EINVAL, "conv op: need square kernel and cin == 3 or cin % 64 == 0");
     HIPCHK(h, hipSetDevice(h->dev));
     const int cs = cin == 3 ? 8 : cin, k = kh;
-    const int P = out_dim(hh, k, stride, pad), Q = out_dim(ww, k, stride, pad);
+    // multi-level form: x is [n][cells][cin], cells = the levels' squares laid end to end (hh = cells, ww = 1)
+    const int P = nlev > 0 ? hh : out_dim(hh, k, stride, pad), Q = nlev > 0 ? 1 : out_dim(ww, k, stride, pad);
     if (P < 1 || Q < 1) return h->fail(YH_EINVAL, "conv op: empty output");
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
@@ -1453,6 +1482,7 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
             else if (rp >= 2 && cout >= 128) tile = TILE_ROWPATCH_128;
         }
     }
+    if (getenv("YH_OP_TILE") && cin != 3) tile = (ConvTile)atoi(getenv("YH_OP_TILE"));   // test hook: force a tile variant
     const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8
     std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
@@ -1492,6 +1522,18 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
         p.N = n; p.H = hh; p.W = ww; p.C = cs; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
         p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad; p.ksteps = Kpad / 64; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
         p.act = act == 1 ? 1 : 0; p.tanh_from = act == 2 ? 0 : INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile);
+        if (nlev > 0) {
+            p.nlev = nlev;
+            for (int l = 0, st = 0; l < nlev; ++l) { p.lev_start[l] = st; p.lev_h[l] = p.lev_w[l] = level_sizes[l]; st += level_sizes[l] * level_sizes[l]; }
+        }
+        // test hook: a forced split-K (the engine decides it in fill_conv_params)
+        const int ksl = getenv("YH_OP_KSLICES") ? atoi(getenv("YH_OP_KSLICES")) : 0;
+        if (ksl > 1 && ksl <= p.ksteps && (size_t)ksl * M * coutPad * 4 <= yh_engine::kSplitKBytes) {
+            p.ksteps_per_slice = (p.ksteps + ksl - 1) / ksl;
+            p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+            p.partial_ld = coutPad;
+            p.partial = h->splitk_ws[0];
+        }
         e = launch_conv_planned(p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
@@ -1500,6 +1542,20 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
     if (e != hipSuccess) return h->fail(YH_EHIP, std::string("conv op: ") + hipGetErrorString(e));
     for (size_t m = 0; m < M; ++m) memcpy(&y[m * cout], &ys[m * cout8], (size_t)cout * 2);
     return YH_OK;
+}
+
+int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint16_t* w,
+                     const float* bias, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                     const uint16_t* residual, int32_t act, uint16_t* y) {
+    return op_conv2d_impl(h, x, n, hh, ww, cin, w, bias, cout, kh, kw, stride, pad, residual, act, y, nullptr, 0);
+}
+
+int yh_op_conv2d_levels_f16(yh_engine* h, const uint16_t* x, int32_t n, const int32_t* level_sizes, int32_t nlev, int32_t cin,
+                            const uint16_t* w, const float* bias, int32_t cout, int32_t k, int32_t act, uint16_t* y) {
+    if (!level_sizes || nlev < 1 || nlev > 5 || cin % 64 != 0 || (k != 1 && k != 3)) return YH_EINVAL;
+    int cells = 0;
+    for (int l = 0; l < nlev; ++l) { if (level_sizes[l] < 1) return YH_EINVAL; cells += level_sizes[l] * level_sizes[l]; }
+    return op_conv2d_impl(h, x, n, cells, 1, cin, w, bias, cout, k, k, 1, k / 2, nullptr, act, y, level_sizes, nlev);
 }
 
 int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t c, int32_t ho, int32_t wo, uint16_t* y) {

@@ -35,6 +35,9 @@ struct ConvParams {
     int M;                // N*P*Q (rows this launch may write: m < M)
     int m_tile0;          // first row tile of this launch (two-phase launches: the tail starts past 0)
     int ch_tile0;         // first channel tile of this launch (channel-split launches), in units of this launch's tile
+    // multi-level input (nlev > 0): the P*Q rows of an image are the cells of nlev pyramid levels laid end to
+    // end (level l: rows lev_start[l].., a lev_h[l] x lev_w[l] image); taps stay inside their level
+    int nlev, lev_start[5], lev_h[5], lev_w[5];
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("yh_op_conv2d_levels_f16", _i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     ("yh_op_maxpool3x3s2_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -310,6 +311,18 @@ class Engine:
         y = np.zeros((n, ho, wo, c), np.uint16)
         self._chk(self.L.yh_op_maxpool3x3s2_f16(self.h, _p(xb), n, hh, ww, c, _p(y)))
         return _bits_f32(y, y.shape)
+
+    def op_conv2d_levels(self, x, level_sizes, w, bias, act=0):
+        """x [n][cells][cin] with cells = sum(s*s for s in level_sizes); w [cout][k][k][cin] -> [n][cells][cout] f32."""
+        n, cells, cin = x.shape
+        cout, k = w.shape[0], w.shape[1]
+        ls = np.ascontiguousarray(level_sizes, np.int32)
+        assert cells == int((ls.astype(np.int64) ** 2).sum())
+        xb, wb = _f16_bits(x), _f16_bits(w)
+        bias = np.ascontiguousarray(bias, np.float32)
+        y = np.zeros((n, cells, cout), np.uint16)
+        self._chk(self.L.yh_op_conv2d_levels_f16(self.h, _p(xb), n, _p(ls), len(ls), cin, _p(wb), _p(bias), cout, k, act, _p(y)))
+        return y.view(np.float16).astype(np.float32)
 
     def op_stem_pool(self, x, w, bias, want_stem=True):
         """x [n][S][S][3], w [64][7][7][3] (f16-representable f32) -> (stem or None, pool) as f32 NHWC."""
