@@ -1436,7 +1436,8 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 h->prof_labels[i] = "splitk_reduce_f16:" + o.name;
                 by = (double)pe.k.p.M * pe.k.p.partial_ld * 4.0 * pe.k.p.k_slices + (double)pe.k.p.M * pe.k.p.cout8 * 2.0;
             } else if (pe.is_conv) {
-                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + ":" + o.name + pe.k.what;
+                // (the multi-level instantiation is a kernel symbol of its own in rocprofv3's stats)
+                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + (pe.k.p.nlev > 0 ? "[ml]" : "") + ":" + o.name + pe.k.what;
             } else h->prof_labels[i] = o.label;
         } else h->prof_labels[i] = detect_stage_name(pe.stage);
         if (flops) flops[i] = fl;

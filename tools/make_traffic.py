@@ -12,7 +12,8 @@ def symbol(name):
         s = ",".join(a[:6])
         if len(a) >= 9 and a[8] == "16":
             s += ",mfma16"
-        return f"conv_igemm_f16<{s}>"
+        ml = "[ml]" if len(a) >= 10 and a[9] == "1" else ""
+        return f"conv_igemm_f16<{s}>{ml}"
     m = re.search(r"(?:yh::|_ZN2yh\d+)([a-z_0-9]+)", name)
     return m.group(1) if m else name[:40]
 
