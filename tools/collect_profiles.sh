@@ -9,20 +9,21 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[1/6] bench"; python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-echo "[2/6] rocprofv3 kernel stats of the bench command"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-cp "$(find $OUT/stats -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats.csv
-echo "[3/6] per-launch tables"
-python3 $R/tools/profile_table.py --batch 64 > $OUT/${TAG}_hipevent_per_launch_batch64.txt
-python3 $R/tools/profile_table.py --batch 1 > $OUT/${TAG}_hipevent_per_launch_batch1.txt
-echo "[4/6] PMC FETCH_SIZE"
+echo "[1/6] PMC FETCH_SIZE"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcF -o run --output-format csv -- python3 $R/tools/pmc_run.py 64 > $OUT/pmcF.log 2>&1
-echo "[5/6] PMC WRITE_SIZE"
+echo "[2/6] PMC WRITE_SIZE"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcW -o run --output-format csv -- python3 $R/tools/pmc_run.py 64 > $OUT/pmcW.log 2>&1
 F=$(find $OUT/pmcF -name "*counter_collection.csv" | sort | tail -1)
 W=$(find $OUT/pmcW -name "*counter_collection.csv" | sort | tail -1)
 python3 $R/tools/make_traffic.py $F $W 64 $OUT/${TAG}_traffic.json > /dev/null
+cp $OUT/${TAG}_traffic.json $R/profiles/${TAG}_traffic.json   # bench.py reads roofline.traffic from profiles/
+echo "[3/6] bench"; python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+echo "[4/6] rocprofv3 kernel stats of the bench command"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+cp "$(find $OUT/stats -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats.csv
+echo "[5/6] per-launch tables"
+python3 $R/tools/profile_table.py --batch 64 > $OUT/${TAG}_hipevent_per_launch_batch64.txt
+python3 $R/tools/profile_table.py --batch 1 > $OUT/${TAG}_hipevent_per_launch_batch1.txt
 echo "[6/6] SQ counters"
 {
   echo "# rocprofv3 --pmc passes over tools/pmc_run.py 16 (batch 16, two eager forwards); sums over all dispatches of each kernel"
