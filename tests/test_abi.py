@@ -55,3 +55,8 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "import oracle" not in txt and "oracle.h" not in txt, os.path.join(dp, f)
                 assert not re.search(r"\borc_[a-z0-9_]+\s*\(", txt), os.path.join(dp, f)  # no oracle call
+    # tools/ are measurement scripts around the product: they do not load the oracle either
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert not re.search(r"import\s+(oracle|tfl_oracle)|liboracle|tfl_oracle as", txt), f

@@ -1,14 +1,15 @@
 """The reference's own model family on the GPU: a full-size synthetic MobileNetV2-FPN-YOLACT .tflite
 (tests/tfl_models.mobilenetv2_yolact: the op census of data/FRC_model_edgetpu.log; the real
 FRC_model.tflite is absent) through the uint8 executor: per-invoke latency (host input copy + graph
-launch + sync), classify() on a 640x480 frame, and the numpy oracle of the same model on the host."""
+launch + sync) and classify() on a 640x480 frame. Parity of this model against the numpy oracle is
+tests/test_gpu_tflite.py::test_full_size_mobilenetv2_yolact_graph (tools/ never load oracle/)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for d in ("tiny-object-detection_amd", "tests", "oracle"):
+for d in ("tiny-object-detection_amd", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import yolact_amd as ya
-import tfl_builder as B, tfl_models as M, tfl_oracle as O
+import tfl_builder as B, tfl_models as M
 
 rng = np.random.default_rng(0)
 model = M.mobilenetv2_yolact(rng)
@@ -18,8 +19,7 @@ x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
 def invoke():
     eng.set_input(x); eng.invoke(); return eng.output(4)
 got = invoke()
-t0 = time.perf_counter(); val = O.run_model(model, {model.inputs[0]: x}); t_cpu = time.perf_counter() - t0
-print(f"{len(model.ops)} ops, {len(buf) / 1e6:.1f} MB model; output 4 equals the numpy oracle: {bool(np.array_equal(got.reshape(-1), val[model.outputs[4]].reshape(-1)))}")
+print(f"{len(model.ops)} ops, {len(buf) / 1e6:.1f} MB model; output 4: {got.shape}, {len(np.unique(got))} distinct codes")
 t = []
 for _ in range(220):
     t0 = time.perf_counter(); invoke(); t.append(time.perf_counter() - t0)
@@ -31,4 +31,3 @@ for _ in range(120):
     f = frame.copy(); t0 = time.perf_counter(); eng.classify_frame(f, 640, 480, ya.COMPAT_SANE); t.append(time.perf_counter() - t0)
 t = np.array(t[20:]) * 1e3
 print(f"classify 640x480 through the .tflite (two tiles): median {np.median(t):.3f} ms, p99 {np.percentile(t, 99):.3f} ms")
-print(f"numpy oracle of the same model on the host (1 process): {t_cpu * 1e3:.0f} ms per 224x224 tile")
