@@ -254,6 +254,10 @@ int yh_op_conv2d_levels_f16(yh_engine* h, const uint16_t* x, int32_t n, const in
  * stem_out[n][SO][SO][64] (the pre-pool tensor, a test hook). */
 int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, const uint16_t* w, const float* bias,
                         uint16_t* stem_out, uint16_t* pool_out);
+/* The same from raw frames rgb[n][S][S][3] uint8: the kernel's loader also does the preprocessing
+ * ((v - mean) / std per channel, rounded to f16), as in production runs. */
+int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                         uint16_t* stem_out, uint16_t* pool_out);
 /* Detection tail alone on caller-provided head outputs (host f16 bits, layouts as outputs 0..3)
  * for n frames; results are then read with yh_read_detections. Lets the tail be checked
  * bit-for-bit against the oracle on identical inputs. */

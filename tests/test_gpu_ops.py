@@ -179,6 +179,24 @@ def test_stem_pool_fused_exact_on_integers(eng, oracle, n, S):
     assert np.array_equal(pool2, pool)
 
 
+@pytest.mark.parametrize("n,S", [(2, 30), (1, 64), (1, 98)])
+def test_stem_pool_with_fused_preprocessing_is_bitwise_the_two_step_path(eng, n, S):
+    """Production runs hand the fused stem raw uint8 frames (its loader normalises them); that must equal,
+    bit for bit, normalising first ((v - mean) / std in f32, rounded to f16: the preprocess kernel's
+    expression) and running the f16 form - image borders included, where the padding is exact zero
+    and NOT a normalised black pixel."""
+    rng = np.random.default_rng(S)
+    rgb = rng.integers(0, 256, (n, S, S, 3), dtype=np.uint8)
+    wt = f16(rng.normal(0, 1, (64, 7, 7, 3)) / 12)
+    b = rng.normal(0, 0.2, 64).astype(np.float32)
+    mean = np.array([123.68, 116.78, 103.94], np.float32); sd = np.array([58.40, 57.12, 57.38], np.float32)
+    x = ((rgb.astype(np.float32) - mean) / sd).astype(np.float16).astype(np.float32)
+    stem_a, pool_a = eng.op_stem_pool_rgb8(rgb, wt, b)
+    stem_b, pool_b = eng.op_stem_pool(x, wt, b)
+    assert np.array_equal(stem_a, stem_b) and np.array_equal(pool_a, pool_b)
+    assert np.abs(stem_a).max() > 0.5
+
+
 def test_stem_pool_fused_vs_oracle_random(eng, oracle):
     rng = np.random.default_rng(5)
     x = f16(rng.normal(0, 1.2, (2, 70, 70, 3)))

@@ -807,7 +807,21 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
             const int gy = by0 + row, gx = bx0 + 2 * cp;
 #pragma unroll
             for (int e = 0; e < 8; ++e) nv[k][e] = (half_t)0.0f;
-            if (i < NCH && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp) nv[k] = *(const half8*)(img + ((long long)gy * p.Wp + gx) * 4);
+            if (p.rgb) {   // fused preprocessing: two pixels of raw RGB -> (v - mean) / std in f16, zero outside the image
+                const int iy = gy - 3;
+                if (i < NCH && (unsigned)iy < (unsigned)p.S) {
+                    const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
+                    const uint8_t* row = p.rgb + ((long long)b * p.S + iy) * p.S * 3;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const int ix = gx + px - 3;
+                        if ((unsigned)ix < (unsigned)p.S) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) nv[k][px * 4 + c] = (half_t)(((float)row[ix * 3 + c] - mean[c]) / sd[c]);
+                        }
+                    }
+                }
+            } else if (i < NCH && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp) nv[k] = *(const half8*)(img + ((long long)gy * p.Wp + gx) * 4);
         }
     };
     auto store_patch = [&]() {

@@ -140,7 +140,7 @@ struct yh_engine {
     hipEvent_t stage_ev[2] = { nullptr, nullptr };
     int stage_idx = 0;
     int last_conv_launches = 0;   // yh_debug_last_conv_launches
-    bool stem_fused = false;
+    bool stem_fused = false, pre_fused = false;
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
@@ -278,7 +278,13 @@ int build_graph_spec(yh_engine* h) {
     if ((rc = new_buf(h, "input", h->in_hp, h->in_hp, 4, &h->in_f16))) return rc;
 
     int ci = 0;  // canonical conv cursor
-    {
+    // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or YH_STEMFUSE=0; its patch
+    // loader then also does the preprocessing (raw RGB -> normalised f16) unless YH_PREFUSE=0.
+    static const int stemfuse = getenv("YH_STEMFUSE") ? atoi(getenv("YH_STEMFUSE")) : 1;
+    static const int prefuse = getenv("YH_PREFUSE") ? atoi(getenv("YH_PREFUSE")) : 1;
+    h->stem_fused = stemfuse && (S % 2 == 0);
+    h->pre_fused = h->stem_fused && prefuse;
+    if (!h->pre_fused) {
         Op o; o.kind = OP_PRE; o.name = "input"; o.label = "preprocess_rgb8_f16:input";
         o.bytes_per_img = (double)S * S * (3 + 8);
         h->ops.push_back(o);
@@ -287,10 +293,7 @@ int build_graph_spec(yh_engine* h) {
     Buf stem, pool;
     if ((rc = new_buf(h, "stem", H1, H1, 64, &stem))) return rc;
     if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
-    // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or YH_STEMFUSE=0; the
-    // "stem" tensor is then only materialised for engines created with debug_tensors = 1 (test hook).
-    static const int stemfuse = getenv("YH_STEMFUSE") ? atoi(getenv("YH_STEMFUSE")) : 1;
-    h->stem_fused = stemfuse && (S % 2 == 0);
+    // (the "stem" tensor is only materialised for engines created with debug_tensors = 1: test hook)
     if (h->stem_fused) {
         Op o;
         o.kind = OP_STEMPOOL; o.name = "pool"; o.label = "stem_pool_f16:stem+pool";
@@ -298,7 +301,7 @@ int build_graph_spec(yh_engine* h) {
         o.in = h->in_f16; o.out = pool; o.res = stem;   // res = optional stem output
         o.P = H2; o.Q = H2;
         o.flops_per_img = 2.0 * H1 * H1 * 64 * 147.0;
-        o.bytes_per_img = 8.0 * h->in_hp * h->in_hp + 2.0 * 64 * H2 * H2;
+        o.bytes_per_img = (h->pre_fused ? 3.0 * S * S : 8.0 * h->in_hp * h->in_hp) + 2.0 * 64 * H2 * H2;
         h->ops.push_back(o);
     } else {
     {
@@ -742,6 +745,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             const Panel& pn = h->panels[o.panel];
             StemPoolParams sp;
             sp.x = o.in.d; sp.w = pn.w; sp.bias = pn.bias; sp.pool = o.out.d;
+            sp.rgb = h->pre_fused ? h->in_u8 : nullptr; sp.S = h->S;
             sp.stem = h->cfg.debug_tensors ? o.res.d : nullptr;
             sp.n = n; sp.Hp = o.in.h; sp.Wp = o.in.w; sp.SO = o.res.h; sp.PO = o.out.h;
             sp.tiles_y = (o.out.h + 7) / 8; sp.tiles_x = (o.out.w + 7) / 8;
@@ -1592,13 +1596,14 @@ int yh_op_maxpool3x3s2_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t h
     return YH_OK;
 }
 
-int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, const uint16_t* w, const float* bias,
-                        uint16_t* stem_out, uint16_t* pool_out) {
-    if (!h || !x || !w || !bias || !pool_out || n < 1 || S < 8 || (S & 1)) return YH_EINVAL;
+static int op_stem_pool_impl(yh_engine* h, const uint16_t* x, const uint8_t* rgb, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                             uint16_t* stem_out, uint16_t* pool_out) {
+    if (!h || (!x && !rgb) || !w || !bias || !pool_out || n < 1 || S < 8 || (S & 1)) return YH_EINVAL;
     HIPCHK(h, hipSetDevice(h->dev));
     const int Hp = S + 8, SO = out_dim(S, 7, 2, 3), PO = out_dim(SO, 3, 2, 1);
     // host-side staging, as the engine does it: zero-bordered 4-channel image, stem panel [64][256]
     std::vector<uint16_t> xs((size_t)n * Hp * Hp * 4, 0), wp((size_t)64 * 256, 0);
+    if (x)
     for (int b = 0; b < n; ++b)
         for (int yy = 0; yy < S; ++yy)
             for (int xx = 0; xx < S; ++xx)
@@ -1608,8 +1613,10 @@ int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, c
             for (int sx = 0; sx < 7; ++sx)
                 for (int c = 0; c < 3; ++c) wp[(size_t)o * 256 + r * 32 + sx * 4 + c] = w[(((size_t)o * 7 + r) * 7 + sx) * 3 + c];
     const size_t ns = (size_t)n * SO * SO * 64, np = (size_t)n * PO * PO * 64;
-    void *dx = nullptr, *dw = nullptr, *db = nullptr, *ds = nullptr, *dp = nullptr;
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *ds = nullptr, *dp = nullptr, *drgb = nullptr;
     hipError_t e = hipMalloc(&dx, xs.size() * 2);
+    if (e == hipSuccess && rgb) e = hipMalloc(&drgb, (size_t)n * S * S * 3);
+    if (e == hipSuccess && rgb) e = hipMemcpy(drgb, rgb, (size_t)n * S * S * 3, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&dw, wp.size() * 2);
     if (e == hipSuccess) e = hipMalloc(&db, 64 * 4);
     if (e == hipSuccess) e = hipMalloc(&ds, ns * 2);
@@ -1622,6 +1629,7 @@ int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, c
     if (e == hipSuccess) {
         StemPoolParams sp;
         sp.x = (const half_t*)dx; sp.w = (const half_t*)dw; sp.bias = (const float*)db; sp.pool = (half_t*)dp;
+        sp.rgb = (const uint8_t*)drgb; sp.S = S;
         sp.stem = stem_out ? (half_t*)ds : nullptr;
         sp.n = n; sp.Hp = Hp; sp.Wp = Hp; sp.SO = SO; sp.PO = PO; sp.tiles_y = (PO + 7) / 8; sp.tiles_x = (PO + 7) / 8;
         sp.x_img_stride = (long long)Hp * Hp * 4; sp.pool_img_stride = (long long)PO * PO * 64; sp.stem_img_stride = (long long)SO * SO * 64;
@@ -1630,9 +1638,18 @@ int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, c
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && stem_out) e = hipMemcpy(stem_out, ds, ns * 2, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(pool_out, dp, np * 2, hipMemcpyDeviceToHost);
-    hipFree(dx); hipFree(dw); hipFree(db); hipFree(ds); hipFree(dp);
+    hipFree(dx); hipFree(dw); hipFree(db); hipFree(ds); hipFree(dp); if (drgb) hipFree(drgb);
     if (e != hipSuccess) return h->fail(YH_EHIP, std::string("stem+pool op: ") + hipGetErrorString(e));
     return YH_OK;
+}
+
+int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                        uint16_t* stem_out, uint16_t* pool_out) {
+    return op_stem_pool_impl(h, x, nullptr, n, S, w, bias, stem_out, pool_out);
+}
+int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S, const uint16_t* w, const float* bias,
+                         uint16_t* stem_out, uint16_t* pool_out) {
+    return op_stem_pool_impl(h, nullptr, rgb, n, S, w, bias, stem_out, pool_out);
 }
 
 int yh_op_detect(yh_engine* h, const uint16_t* loc, const uint16_t* conf, const uint16_t* mask, const uint16_t* proto, int32_t n) {

@@ -63,6 +63,8 @@ hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream);
 // Fused stem: 7x7 stride-2 conv (3 -> 64 channels, bias, ReLU) + 3x3 stride-2 max pool, one kernel.
 struct StemPoolParams {
     const half_t* x;      // [n][Hp][Wp][4] f16, image at (+3, +3) inside a zero border (preprocess_rgb8_f16)
+    const uint8_t* rgb;   // if not null: the raw frames [n][S][S][3] instead of x; the patch loader normalises them itself
+    int S;                //   (same expression as preprocess_rgb8_f16; the border is exact zero)
     const half_t* w;      // stem panel [64][256]: K index = r * 32 + s * 4 + c, zero for s == 7, c == 3, r == 7
     const float* bias;    // [64]
     half_t* pool;         // [n][PO][PO][64]

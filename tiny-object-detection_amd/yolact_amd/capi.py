@@ -86,6 +86,7 @@ SYMBOLS = [
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_conv2d_levels_f16", _i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -334,6 +335,20 @@ class Engine:
         stem = np.zeros((n, so, so, 64), np.uint16) if want_stem else None
         pool = np.zeros((n, po, po, 64), np.uint16)
         self._chk(self.L.yh_op_stem_pool_f16(self.h, _p(xb), n, S, _p(wb), _p(bias), _p(stem) if want_stem else None, _p(pool)))
+        f = lambda a: a.view(np.float16).astype(np.float32)
+        return (f(stem) if want_stem else None), f(pool)
+
+    def op_stem_pool_rgb8(self, rgb, w, bias, want_stem=True):
+        """rgb [n][S][S][3] uint8 (preprocessing fused into the kernel) -> (stem or None, pool) as f32 NHWC."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        n, S = rgb.shape[0], rgb.shape[1]
+        so = (S + 6 - 7) // 2 + 1
+        po = (so + 2 - 3) // 2 + 1
+        wb = _f16_bits(w)
+        bias = np.ascontiguousarray(bias, np.float32)
+        stem = np.zeros((n, so, so, 64), np.uint16) if want_stem else None
+        pool = np.zeros((n, po, po, 64), np.uint16)
+        self._chk(self.L.yh_op_stem_pool_rgb8(self.h, _p(rgb), n, S, _p(wb), _p(bias), _p(stem) if want_stem else None, _p(pool)))
         f = lambda a: a.view(np.float16).astype(np.float32)
         return (f(stem) if want_stem else None), f(pool)
 
