@@ -87,34 +87,6 @@ def test_conv_exact_on_integers_big_tiles(eng, oracle, cin, cout, k):
     assert np.array_equal(y, yo)
 
 
-@pytest.mark.parametrize("mode,n,h,w,cin,cout,res", [
-    ("1", 3, 13, 11, 128, 256, True),     # tiles straddle images, ragged M
-    ("1", 2, 40, 1, 64, 256, False),      # one-pixel-wide rows: every horizontal neighbour is padding
-    ("1", 1, 1, 300, 64, 512, True),      # one-row images, two channel tiles
-    ("1", 5, 17, 16, 64, 256, False),     # W divides the tile
-    ("2", 3, 13, 11, 128, 128, True),     # 128-channel variant (single-pass epilogue)
-    ("2", 2, 23, 19, 64, 351, False),     # channel tail
-])
-def test_conv_rowpatch_exact_on_integers(eng, oracle, mode, n, h, w, cin, cout, res):
-    """The shared-patch 3x3 stride-1 kernel (YH_ROWPATCH): border taps are masked per fragment lane
-    rather than per DMA row, so sweep the geometries where patch rows cross image rows / images."""
-    import os
-    rng = np.random.default_rng(h * 31 + w)
-    x = rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)
-    wt = rng.integers(-2, 3, (cout, 3, 3, cin)).astype(np.float32)
-    b = rng.integers(-4, 5, cout).astype(np.float32)
-    r = rng.integers(-5, 6, (n, h, w, cout)).astype(np.float32) if res else None
-    old = os.environ.get("YH_ROWPATCH")
-    os.environ["YH_ROWPATCH"] = mode
-    try:
-        y = eng.op_conv2d(f16(x), f16(wt), b, 1, 1, None if r is None else f16(r), 1)
-    finally:
-        if old is None: os.environ.pop("YH_ROWPATCH")
-        else: os.environ["YH_ROWPATCH"] = old
-    yo = oracle.conv2d(f16(x), f16(wt), b, 1, 1, None if r is None else f16(r), 1, f16=True)
-    assert np.array_equal(y, yo)
-
-
 @pytest.mark.parametrize("cin,cout,k,n,h,w", [
     (64, 256, 3, 5, 17, 16),     # 6 row tiles on "4 CUs": one whole round on the big tile + a tail on 128x128 tiles
     (512, 512, 1, 5, 16, 16),    # two channel tiles x 5 row tiles: 2 rounds + a tail of 2 workgroups

@@ -63,14 +63,11 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     constexpr int XL = TM / RSTEP, WL = TCH / RSTEP;  // LDS-DMA instructions per thread per tile
     constexpr int AB_BYTES = (TCH + TM) * 128;
     constexpr int ES = TCH + 4;                    // epilogue row stride in floats
-    // STAGES == 5 ("X3W2"): weights double-buffered, activations in a ring of three (one step more
-    // lead for the stream that misses L2); 2 * TCH + 3 * TM rows of 128 B.
-    constexpr int RING_BYTES = STAGES == 5 ? (2 * TCH + 3 * TM) * 128 : STAGES * AB_BYTES;
+    constexpr int RING_BYTES = STAGES * AB_BYTES;
     constexpr int LDS_BYTES = cmax<RING_BYTES, (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
     static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
-    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4 || STAGES == 5) && !SMALLC), "ring variants: no ordinary loads may share the loop");
-    static_assert(STAGES != 5 || !SPLITK, "X3W2 has no split-K form");
+    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && !SMALLC), "ring variants: no ordinary loads may share the loop");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -269,78 +266,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             __syncthreads();  // all waves done with buf[cur]; DMA into buf[cur^1] landed
             cur ^= 1;
         }
-    } else if (STAGES == 5) {
-        // X3W2: the activation stream is the one that misses L2 (tap re-reads of lines that left the
-        // XCD's L2; dropping it alone recovers most of the exposed time, dropping W alone little),
-        // so X runs TWO steps ahead in a ring of three while W stays double-buffered. Step k issues
-        // W(k+1) then X(k+2) (in that order, sliced between the MFMA groups) and ends with a counted
-        // s_waitcnt vmcnt(XL): everything but the XL youngest DMAs (= X(k+2)) has landed, i.e.
-        // W(k+1) and the older X(k+1); a raw s_barrier publishes them and frees stage k.
-        constexpr int WB = TCH * 128, XB = TM * 128;
-        struct Pos { int kr, ks, kc; };
-        Pos pw = { kr, ks, kc }, px = { kr, ks, kc };
-        auto adv = [&](Pos& q) { if (++q.ks == p.S) { q.ks = 0; if (++q.kr == p.R) { q.kr = 0; q.kc += 64; } } };
-        auto issue_w = [&](int stage, int d, const Pos& q) {
-            const int wk = (q.kr * p.S + q.ks) * p.C + q.kc;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, lds3 + stage * WB + wave * 1024 + d * (RSTEP * 128), 16,
-                                                     (int)(wbase + (unsigned)((RSTEP * d) * p.ldw + wk) * 2u), 0, 0, 0);
-        };
-        auto issue_x = [&](int stage, int i, const Pos& q) {
-            const int off = (q.kr * p.W + q.ks) * p.C + q.kc;
-            const bool ok = (unsigned)(xih[i] + q.kr) < (unsigned)p.H && (unsigned)(xiw[i] + q.ks) < (unsigned)p.W;
-            const unsigned voff = ok ? (unsigned)(xbase[i] + off) * 2u : p.x_zero_off;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, lds3 + 2 * WB + stage * XB + wave * 1024 + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
-        };
-        const int nk = nk_total;
-#pragma unroll
-        for (int i = 0; i < XL; ++i) issue_x(0, i, px);
-        adv(px);
-#pragma unroll
-        for (int d = 0; d < WL; ++d) issue_w(0, d, pw);
-        adv(pw);
-        if (nk > 1) {
-#pragma unroll
-            for (int i = 0; i < XL; ++i) issue_x(1, i, px);
-            adv(px);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XL) : "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        int ws = 0, xs = 0, xs2 = 2;   // stage of W(k), of X(k), of X(k+2)
-        const int b_rel = b_row - TCH * 128;
-        for (int k = 0; k < nk; ++k) {
-            const bool mw = k + 1 < nk, mx = k + 2 < nk;
-            const char* base_w = lds + ws * WB;
-            const char* base_x = lds + 2 * WB + xs * XB;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int co = ((KG * kk + lh) ^ swz) << 4;
-                half8 a[TC], b[TMT];
-#pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base_w + a_row + i * TSTR + co);
-#pragma unroll
-                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base_x + b_rel + j * TSTR + co);
-#pragma unroll
-                for (int d = (kk * NDMA) / KS; d < ((kk + 1) * NDMA) / KS; ++d) {
-                    if (d < WL) { if (mw) issue_w(ws ^ 1, d, pw); }
-                    else if (mx) issue_x(xs2, d - WL, px);
-                }
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMT; ++j) acc[i][j] = mfma_f16<MT>(a[i], b[j], acc[i][j]);
-            }
-            if (mw) adv(pw);
-            if (mx) { adv(px); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XL) : "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's fragment reads of step k are done
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            ws ^= 1;
-            xs = xs == 2 ? 0 : xs + 1;
-            xs2 = xs2 == 2 ? 0 : xs2 + 1;
-        }
-        __syncthreads();  // LDS is reused by the epilogue
     } else {
         // 3-stage ring + register double buffering of the MFMA fragments:
         //   step k:  wait(tile k+1 landed) ; lgkmcnt(0) ; barrier ; DMA tile k+3 -> stage of tile k ;
@@ -471,257 +396,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
-                if (m < p.M) {
-                    const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-                    long long yo, ro;
-                    offsets(m, yo, ro);
-                    if (p.res) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-                    }
-                    if (ch + 8 > p.tanh_from) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (ch + e >= p.tanh_from) v[e] = spec_tanhf(v[e]);
-                    }
-                    half8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                    *(half8*)(p.y + yo) = o;
-                }
-            }
-        }
-        if (h + 1 < EPI) __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv_rowpatch_f16 — stride-1 convolutions with kernel width S >= 2 (the 3x3 layers: ~60 % of the
-// FLOPs). The generic kernel above is bound by the L2 -> LDS fill RATE (dropping either operand
-// stream with a zero-record descriptor recovers most of the exposed time; more prefetch lead does
-// not). The S taps of one kernel row read the same TM pixels shifted by one, so here a patch of
-// TM + S - 1 pixel rows is DMA'd once per (64-channel chunk, r) and the S steps of that row read
-// their B fragments from it at row offset +s: the activation fill drops by (S-1)/S and the DMA
-// instructions per step from 8 to 4 + 5/S. Border taps (which the generic kernel redirects to the
-// zero block per DMA lane) cannot be decided per patch row any more - one row serves different
-// output pixels at different s - so they are masked at fragment-read time from a per-lane validity
-// bit per (r, s), and only in waves where some lane needs it (wave-uniform ballot).
-// Tile: TCH x 256 pixels, 8 waves (2 x 4), v_mfma_f32_16x16x32_f16, weights double-buffered, patches
-// double-buffered (320 rows each: 5 DMA pieces per wave, so one counted vmcnt fits every wave).
-// ------------------------------------------------------------------------------------------------
-template <int TCH, int EPI, int S>
-__global__ __launch_bounds__(512, 2) void conv_rowpatch_f16(const ConvParams p) {
-    constexpr int TM = 256, WCH = 2, WM = 4, NT = 512, MT = 16, KS = 2, KG = 4;
-    constexpr int WTC = TCH / WCH, WTM = TM / WM, TC = WTC / MT, TMT = WTM / MT;
-    constexpr int WL = TCH / 64;                   // W DMA instructions per thread per step
-    constexpr int WB = TCH * 128, PROWS = 320, XB = PROWS * 128, NXP = PROWS / 64;
-    constexpr int ES = TCH + 4;
-    constexpr int LDS_BYTES = cmax<2 * WB + 2 * XB, (TM / EPI) * ES * 4>::v;
-    static_assert(LDS_BYTES <= 160 * 1024 && WM % EPI == 0, "LDS");
-    typedef float accv __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ch_tile = wg % p.n_ch_tiles + p.ch_tile0, m_tile = wg / p.n_ch_tiles + p.m_tile0;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int HW = p.H * p.W, m0 = m_tile * TM, NHW = p.N * HW;
-    const int R = p.R, pad = p.pad;   // S (kernel width) is a template constant: the S steps of a patch are unrolled
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
-    typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* const lds3 = (lds_char*)lds;
-
-    // ---- W staging (as in the generic kernel): thread -> row (tid >> 3) + 64 d, physical chunk tid & 7
-    const int rbw = tid >> 3, lcw = (tid & 7) ^ ((rbw >> 1) & 7);
-    const unsigned wbase = (unsigned)(((ch_tile * TCH + rbw) * p.ldw + lcw * 8) * 2);
-    // ---- patch staging: piece (rd * 8 + wave) = 8 patch rows; thread -> patch row j, physical chunk lane & 7
-    int pj[NXP];           // patch row of this thread in round rd
-#pragma unroll
-    for (int rd = 0; rd < NXP; ++rd) pj[rd] = (rd * 8 + wave) * 8 + (lane >> 3);
-
-    // ---- fragment lane maps
-    const int wid = tid >> 6, wc = wid / WM, wm = wid % WM;
-    const int l15 = lane & 15, lh = lane >> 4;
-    const int a_row = (wc * WTC + l15) * 128, a_swz = (l15 >> 1) & 7;
-    // B fragment byte offsets inside a patch for tap s (row + s, swizzle of that row), k-slice 0; k-slice 1 is ^ 64
-    int b_off[S][TMT];
-#pragma unroll
-    for (int sx = 0; sx < S; ++sx)
-#pragma unroll
-        for (int j = 0; j < TMT; ++j) {
-            const int row = wm * WTM + j * MT + l15 + sx;
-            b_off[sx][j] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
-        }
-    // validity bits of this lane's TMT output pixels: bit (r * S + s)
-    unsigned vbits[TMT];
-#pragma unroll
-    for (int j = 0; j < TMT; ++j) {
-        const int m = m0 + wm * WTM + j * MT + l15;
-        unsigned v = 0;
-        if (m < p.M) {
-            const int n = m / HW, rem = m - n * HW, py = rem / p.W, qx = rem - py * p.W;
-            for (int r = 0; r < R; ++r)
-                for (int sx = 0; sx < S; ++sx)
-                    if ((unsigned)(py + r - pad) < (unsigned)p.H && (unsigned)(qx + sx - pad) < (unsigned)p.W) v |= 1u << (r * S + sx);
-        }
-        vbits[j] = v;
-    }
-
-    accv acc[TC][TMT];
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-#pragma unroll
-        for (int j = 0; j < TMT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
-
-    auto issue_w = [&](int stage, int d, int wk) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, lds3 + stage * WB + wave * 1024 + d * 8192, 16,
-                                                 (int)(wbase + (unsigned)((64 * d) * p.ldw + wk) * 2u), 0, 0, 0);
-    };
-    // patch (kc, r): patch row j holds input pixel g = m0 + (r - pad) W - pad + j of the flattened [N*H*W] image
-    auto issue_patch = [&](int buf, int rd, int kc, int r) {
-        const int j = pj[rd], g = m0 + (r - pad) * p.W - pad + j;
-        unsigned voff = p.x_zero_off;
-        if (j < TM + S - 1 && (unsigned)g < (unsigned)NHW) {
-            const int n = g / HW, loc = g - n * HW;
-            const int lc = (lane & 7) ^ ((j >> 1) & 7);   // source-side swizzle of the lane-linear DMA image
-            voff = (unsigned)((int)(n * p.x_img_stride) + loc * p.C + kc + lc * 8) * 2u;
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, lds3 + 2 * WB + buf * XB + (rd * 8 + wave) * 1024, 16, (int)voff, 0, 0, 0);
-    };
-
-    const int nchunks = p.C >> 6, npatches = nchunks * R;
-    // prologue: W of step 0, patch 0
-#pragma unroll
-    for (int d = 0; d < WL; ++d) issue_w(0, d, 0);
-#pragma unroll
-    for (int rd = 0; rd < NXP; ++rd) issue_patch(0, rd, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int ws = 0, xb = 0, kc = 0, r = 0;
-    for (int pt = 0; pt < npatches; ++pt) {
-        // next patch position
-        int r2 = r + 1, kc2 = kc;
-        if (r2 == R) { r2 = 0; kc2 += 64; }
-        const bool more_patch = pt + 1 < npatches;
-#pragma unroll
-        for (int sx = 0; sx < S; ++sx) {
-            const bool last_step = !more_patch && sx == S - 1;
-            // K position of the NEXT step's weights
-            const int wk_next = sx + 1 < S ? (r * S + sx + 1) * p.C + kc : (r2 * S) * p.C + kc2;
-            const char* base_w = lds + ws * WB;
-            const char* base_x = lds + 2 * WB + xb * XB;
-            const unsigned bit = 1u << (r * S + sx);
-            bool need_mask = false;
-#pragma unroll
-            for (int j = 0; j < TMT; ++j) need_mask = need_mask || !(vbits[j] & bit);
-            const bool wave_mask = __ballot(need_mask) != 0ull;   // wave-uniform
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                half8 a[TC], b[TMT];
-                const int aco = ((KG * kk + lh) ^ a_swz) << 4;
-#pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(base_w + a_row + i * (MT * 128) + aco);
-#pragma unroll
-                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(base_x + (b_off[sx][j] ^ (kk << 6)));
-                if (wave_mask) {
-#pragma unroll
-                    for (int j = 0; j < TMT; ++j)
-                        if (!(vbits[j] & bit)) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) b[j][e] = (half_t)0.0f;
-                        }
-                }
-                if (!last_step) {
-#pragma unroll
-                    for (int d = (kk * WL) / KS; d < ((kk + 1) * WL) / KS; ++d) issue_w(ws ^ 1, d, wk_next);
-                }
-                if (kk == KS - 1 && sx == 0 && more_patch) {
-#pragma unroll
-                    for (int rd = 0; rd < NXP; ++rd) issue_patch(xb ^ 1, rd, kc2, r2);
-                }
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMT; ++j) acc[i][j] = mfma_f16<MT>(a[i], b[j], acc[i][j]);
-            }
-            // W(next) was issued before the patch pieces: all but the NXP youngest DMAs must land now;
-            // the patch has until the end of the following step (a later vmcnt(0) retires it in order)
-            if (sx == 0 && more_patch && S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            ws ^= 1;
-        }
-        xb ^= 1;
-        r = r2; kc = kc2;
-    }
-    __syncthreads();
-
-    // ---- epilogue (same scheme as the generic kernel): f32 [m][ch] image in LDS, coalesced f16 rows
-    float* E = (float*)lds;
-    constexpr int TPR = TCH / 8, RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
-    const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
-    const int ch = ch_tile * TCH + ch_l;
-    const bool ch_ok = ch < p.cout8;
-    const int PQ = p.P * p.Q;
-    float bias8[8];
-    {
-        const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
-    }
-    auto offsets = [&](int m, long long& yo, long long& ro) {
-        if (p.y_dense) { yo = (long long)m * p.ldy + ch; ro = (long long)m * p.ldres + ch; }
-        else {
-            const int n = m / PQ, rem = m - n * PQ;
-            yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
-            ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
-        }
-    };
-#pragma unroll
-    for (int h = 0; h < EPI; ++h) {
-        half8 rv[NPASS];
-        if (p.res && ch_ok) {
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int m = m0 + h * EROWS + pass * RPP + rr;
-                long long yo, ro;
-                offsets(m < p.M ? m : 0, yo, ro);
-                rv[pass] = *(const half8*)(p.res + ro);
-            }
-        }
-        if (EPI == 1 || wm / WMG == h) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TMT; ++j) {
-                    const int m_l = (wm % WMG) * WTM + j * MT + l15;
-                    const int c_l = wc * WTC + i * MT + 4 * lh;
-                    f32x4 v = { acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3] };
-                    *(f32x4*)(E + m_l * ES + c_l) = v;
-                }
-        }
-        __syncthreads();
-        if (ch_ok) {
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int m_l = pass * RPP + rr, m = m0 + h * EROWS + m_l;
                 if (m < p.M) {
                     const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
                     float v[8];
@@ -945,12 +619,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: case TILE_ROWPATCH_128: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
-                 case TILE_32x256: return 32; case TILE_256x128: case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_X3: case TILE_ROWPATCH_256: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
+                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x128: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -958,15 +632,11 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_64x256: return "conv_igemm_f16<64,256,1,4,0,2>";
         case TILE_32x256: return "conv_igemm_f16<32,256,1,4,0,2>";
         case TILE_64x256_SMALLC: return "conv_igemm_f16<64,256,1,4,1,2>";
-        case TILE_256x128: return "conv_igemm_f16<256,128,4,2,0,3>";
         case TILE_128x256: return "conv_igemm_f16<128,256,2,4,0,3>";
         case TILE_256x256: return "conv_igemm_f16<256,256,2,4,0,2>";
         case TILE_256x256_M16: return "conv_igemm_f16<256,256,2,4,0,2,mfma16>";
-        case TILE_256x256_X3: return "conv_igemm_f16<256,256,2,4,0,x3w2,mfma16>";
         case TILE_128x128_M16: return "conv_igemm_f16<128,128,2,2,0,2,mfma16>";
         case TILE_128x128_S3_M16: return "conv_igemm_f16<128,128,2,2,0,3,mfma16>";
-        case TILE_ROWPATCH_256: return "conv_rowpatch_f16<256,2>";
-        case TILE_ROWPATCH_128: return "conv_rowpatch_f16<128,1>";
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
         case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
@@ -1025,7 +695,6 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true, 2, 1>), grid, dim3(256), 0, stream, p); break;
-        case TILE_256x128: hipLaunchKernelGGL((conv_igemm_f16<256, 128, 4, 2, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
@@ -1034,9 +703,6 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
-        case TILE_ROWPATCH_256: hipLaunchKernelGGL((conv_rowpatch_f16<256, 2, 3>), grid, dim3(512), 0, stream, p); break;
-        case TILE_ROWPATCH_128: hipLaunchKernelGGL((conv_rowpatch_f16<128, 1, 3>), grid, dim3(512), 0, stream, p); break;
-        case TILE_256x256_X3: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 5, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;
         default: return hipErrorInvalidValue;

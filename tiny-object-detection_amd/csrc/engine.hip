@@ -552,14 +552,6 @@ ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0, bool ml 
     return t;
 }
 ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml) {
-    // stride-1 k x k (k odd, 'same' padding) layers: the row-patch kernel shares one activation patch
-    // between the k taps of a kernel row (conv_igemm.hip). A/B switch: YH_ROWPATCH=0 disables.
-    static const int rowpatch = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;   // measured slower: off
-    if (rowpatch && !ml && stride == 1 && pn.k == 3 && pad == 1 && pn.cin_store % 64 == 0) {
-        if (pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) >= 192) return TILE_ROWPATCH_256;
-        if (rowpatch >= 2 && (pn.tile == TILE_128x256 || pn.tile == TILE_256x256 || pn.tile == TILE_128x128) &&
-            (long long)((M + 255) / 256) * (pn.coutPad / 128) >= 192) return TILE_ROWPATCH_128;
-    }
     if (pn.tile == TILE_256x256 || pn.tile == TILE_128x256) {
         const int tm = conv_tile_m(pn.tile), tch = conv_tile_ch(pn.tile);
         const long long blocks = (long long)((M + tm - 1) / tm) * (pn.coutPad / tch);
@@ -575,8 +567,6 @@ ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml) {
         if (b128 <= 256) return TILE_128x128_S3;
     }
     static const int mfma16 = getenv("YH_MFMA16") ? atoi(getenv("YH_MFMA16")) : 1;   // A/B switch (tools/): default 16x16x32
-    static const int x3 = getenv("YH_X3") ? atoi(getenv("YH_X3")) : 0;   // A/B switch (tools/): X3W2 ring
-    if (pn.tile == TILE_256x256 && x3 && !ml) return TILE_256x256_X3;
     if (pn.tile == TILE_256x256 && (mfma16 || ml)) return TILE_256x256_M16;
     return pn.tile;
 }
@@ -1477,16 +1467,8 @@ static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
     if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
-    if (tile == TILE_256x256 && getenv("YH_X3") && atoi(getenv("YH_X3"))) tile = TILE_256x256_X3;
-    else if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
+    if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
     if (tile == TILE_128x256 && stride == 1 && !(getenv("YH_128X256_M16") && !atoi(getenv("YH_128X256_M16")))) tile = TILE_128x256_M16;
-    {   // the op test reaches the row-patch kernel the same way the engine does (no grid-size floor here)
-        const int rp = getenv("YH_ROWPATCH") ? atoi(getenv("YH_ROWPATCH")) : 0;
-        if (rp && k == 3 && stride == 1 && pad == 1 && cin % 64 == 0) {
-            if (cout % 256 == 0 && Kpad >= 512) tile = TILE_ROWPATCH_256;
-            else if (rp >= 2 && cout >= 128) tile = TILE_ROWPATCH_128;
-        }
-    }
     if (getenv("YH_OP_TILE") && cin != 3) tile = (ConvTile)atoi(getenv("YH_OP_TILE"));   // test hook: force a tile variant
     const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8

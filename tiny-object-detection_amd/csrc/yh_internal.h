@@ -52,7 +52,8 @@ struct ConvParams {
     float* partial;       // [k_slices][M][partial_ld] f32 workspace
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_256x128 = 4, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8, TILE_256x256_X3 = 9, TILE_ROWPATCH_256 = 10, TILE_ROWPATCH_128 = 11,
+// (ids 4 and 9-11 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel - DESIGN.md §4)
+enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8,
                 TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17 };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
