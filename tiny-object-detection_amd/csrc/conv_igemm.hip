@@ -7,10 +7,10 @@
 //
 //   D[ch][m] = sum_k Wt[ch][k] * X[m][k]     (weights are the MFMA A operand, activations B)
 //
-// Work decomposition: one 256-thread workgroup (4 waves, one per SIMD) owns a TCH x TM output
-// tile; each wave owns (TCH/WCH) x (TM/WM) of it as 32x32 v_mfma_f32_32x32x16_f16 tiles with f32
-// accumulators. K advances 64 at a time (one 128-byte row segment per tile row): global -> LDS
-// directly by LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane, 8 lanes per 128-B line, no VGPR
+// Work decomposition: one workgroup of 4 or 8 waves (WCH x WM) owns a TCH x TM output tile; each wave
+// owns (TCH/WCH) x (TM/WM) of it as 32x32 (v_mfma_f32_32x32x16_f16) or 16x16 (v_mfma_f32_16x16x32_f16)
+// MFMA tiles with f32 accumulators. K advances 64 at a time (one 128-byte row segment per tile row):
+// global -> LDS directly by LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane, 8 lanes per 128-B line, no VGPR
 // staging, no ds_write), double buffered, one barrier per step, the DMA of step k+1 in flight
 // under the MFMAs of step k. LDS rows are 128 B; logical 16-byte chunk c of row r lives at physical
 // chunk (c ^ ((r >> 1) & 7)): the DMA image is lane-linear, so the permutation is applied to each
@@ -35,6 +35,10 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 // STAGES == 3: ring of three; the DMA of step k+2 is issued while step k computes, each step waits
 //              only for ITS tile with a counted s_waitcnt vmcnt(N) (N = this wave's DMA instructions
 //              per tile) and a raw s_barrier, so one tile stays in flight across every barrier.
+//              (STAGES == 4: the same with two tiles in flight; measured neutral, kept as a switch.)
+// ML: multi-level input - the rows of an image are the cells of up to five pyramid levels laid end
+//              to end; every staged row carries its own level's height and width, so a tap never
+//              leaves the level (the shared prediction head as one launch over the whole pyramid).
 // EPI: the epilogue's f32 staging image covers TM / EPI rows at a time (a 256 x 256 tile's does not
 //      fit in LDS at once).
 template <int MT, class ACC>
