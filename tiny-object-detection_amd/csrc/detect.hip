@@ -150,10 +150,18 @@ __device__ unsigned long long radix_select_kth(KeyFn key_of, int n, int k, int* 
     for (int shift = 56; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256; i += NT) hist[i] = 0;
         __syncthreads();
+        // run-length aggregation per lane: the high bytes of score keys (sign, exponent) take two or three
+        // values, and one LDS atomic per key on the same bin serialises the whole pass
+        int run_bin = -1, run_cnt = 0;
         for (int i = tid; i < n; i += NT) {
             const unsigned long long key = key_of(i);
-            if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+            if ((key & mask) == prefix) {
+                const int bin = (int)((key >> shift) & 255ull);
+                if (bin == run_bin) ++run_cnt;
+                else { if (run_cnt) atomicAdd(&hist[run_bin], run_cnt); run_bin = bin; run_cnt = 1; }
+            }
         }
+        if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
         __syncthreads();
         if (tid < 64) {
             const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
     __shared__ unsigned long long sel[YH_TOPK_MAX];     // the K selected keys, then sorted
     __shared__ unsigned long long sorted[YH_TOPK_MAX];
     __shared__ float4 sel_box[YH_TOPK_MAX];
+    __shared__ int supp[YH_TOPK_MAX];
     __shared__ int hist[256];
     __shared__ int sh[4];
     const int list = blockIdx.x;  // b*(C-1) + c
@@ -247,12 +256,31 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
         sel_box[tid] = bx;
     }
     __syncthreads();
+    // Fast-NMS: box j survives iff no better-ranked box i < j overlaps it by more than the threshold.
+    // The K (K - 1) / 2 pairs are dealt evenly over the workgroup (row j has j pairs: rows j and K - j
+    // are folded into one row of K), each hit sets a flag; a lane per row would make the last lane walk
+    // K - 1 boxes while the first walks none (30-60 us of the kernel at K = 200).
+    for (int j = tid; j < YH_TOPK_MAX; j += 256) supp[j] = 0;
+    __syncthreads();
+    {
+        const int half_rows = (K - 1) / 2, folded = half_rows * K;
+        for (int t = tid; t < folded; t += 256) {
+            const int r = t / K, c = t - r * K, j0 = r + 1;
+            const int j = c < j0 ? j0 : K - j0, i = c < j0 ? c : c - j0;
+            if (box_iou(sel_box[i], sel_box[j]) > p.nms_thresh) supp[j] = 1;
+        }
+        if ((K & 1) == 0 && K >= 2) {   // the unpaired middle row
+            const int j = K / 2;
+            for (int i = tid; i < j; i += 256)
+                if (box_iou(sel_box[i], sel_box[j]) > p.nms_thresh) supp[j] = 1;
+        }
+    }
+    __syncthreads();
     for (int j = tid; j < p.top_k; j += 256) {
         float out = -1.0f;
         if (j < K) {
             const float4 bj = sel_box[j];
-            bool keep = true;
-            for (int i = 0; i < j; ++i) keep = keep && !(box_iou(sel_box[i], bj) > p.nms_thresh);
+            const bool keep = supp[j] == 0;
             if (keep) {
                 out = __uint_as_float((unsigned)(sorted[j] >> 32));
                 p.surv_prior[so + j] = (int)(0xFFFFFFFFu - (unsigned)(sorted[j] & 0xFFFFFFFFull));
@@ -344,7 +372,11 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
         for (int e = 0; e < 8; ++e) pv[q * 8 + e] = (float)v[e];
     }
     uint8_t* mo = p.masks + (long long)b * p.max_dets * npx + px;
-    for (int d = 0; d < nd; ++d) {
+    // small batches: the detections are dealt over gridDim.z groups so that more than hp*wp/256
+    // workgroups exist (one frame: 75 workgroups on 256 CUs otherwise)
+    const int per = (p.max_dets + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int d0 = (int)blockIdx.z * per, d1 = d0 + per < nd ? d0 + per : nd;
+    for (int d = d0; d < d1; ++d) {
         const float4 c = crop[d];
         const bool inside = fx >= c.x && fx < c.y && fy >= c.z && fy < c.w;
         float acc = 0.0f;
@@ -377,7 +409,7 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
         }
         case 2: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
         case 3: hipLaunchKernelGGL(det_frame_top, dim3((unsigned)p.n), dim3(1024), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
