@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--backbone", type=int, default=50, choices=(50, 101), help="50: YOLACT-550 R50 (default); 101 with --size 700: configs[4] geometry in f16")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--no-batch1", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N > 1 path on a single-GPU box: every rank uses cuda:0 and the "
@@ -324,7 +325,7 @@ def main():
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], eng_out=aux["dets_frame0"])
+        line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"])
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

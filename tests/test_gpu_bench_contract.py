@@ -1,0 +1,36 @@
+"""-m gpu: bench.py's output contract (the driver parses exactly one JSON line from it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--cpu-budget", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["unit"] == "frames/s" and b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 1
+    assert b["higher_is_better"] is True and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["dtype"] == "f16" and b["data"] == "synthetic" and "workload" in b["config"] and "model" not in b["config"]
+    assert b["value"] > 0 and abs(b["value"] - 8 * 3 / (b["ms_per_step"] * 3e-3)) < 0.01 * b["value"]
+    rf = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["engine_vs_oracle_same_frame"]["mask_iou_matched"] >= 0.99
+    assert b["batch1"]["value"] > 0
