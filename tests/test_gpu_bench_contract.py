@@ -34,3 +34,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(built):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["engine_vs_oracle_same_frame"]["mask_iou_matched"] >= 0.99
     assert b["batch1"]["value"] > 0
+
+
+def test_graft_entry_smoke_runs(built):
+    """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
