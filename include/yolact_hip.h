@@ -258,6 +258,9 @@ int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, c
  * ((v - mean) / std per channel, rounded to f16), as in production runs. */
 int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S, const uint16_t* w, const float* bias,
                          uint16_t* stem_out, uint16_t* pool_out);
+/* Groundwork for an fp8 convolution path (not used by the forward yet): y[i] = OCP FP8 E4M3 code of
+ * x[i] * inv_scale (x: f16 bits), round to nearest even, saturating at +-448, NaN -> 0x7F | sign. */
+int yh_op_quantize_e4m3(yh_engine* h, const uint16_t* x, size_t n, float inv_scale, uint8_t* y);
 /* Detection tail alone on caller-provided head outputs (host f16 bits, layouts as outputs 0..3)
  * for n frames; results are then read with yh_read_detections. Lets the tail be checked
  * bit-for-bit against the oracle on identical inputs. */

@@ -298,3 +298,23 @@ def detect(loc, conf, mask, proto, priors, num_classes=81, top_k=200, max_dets=1
                           C.cast(dets, C.c_void_p), _p(masks) if want_masks else None)
     out = [dict(class_id=d.class_id, prior=d.prior, score=d.score, box=tuple(d.box)) for d in dets[:nd]]
     return out, (masks[:nd] if want_masks else None)
+
+
+# ---- OCP FP8 E4M3 (orc_fp8.c) --------------------------------------------------------------------
+def e4m3_decode_table():
+    """The 256 decoded values (NaN at 0x7F / 0xFF)."""
+    L = lib()
+    L.orc_e4m3_to_f32.restype = C.c_float
+    L.orc_e4m3_to_f32.argtypes = [C.c_uint8]
+    return np.array([L.orc_e4m3_to_f32(b) for b in range(256)], np.float32)
+
+
+def quantize_e4m3(x, inv_scale=1.0):
+    """uint8 codes of round-to-nearest-even, saturating e4m3 of x * inv_scale (f32 multiply)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros(x.shape, np.uint8)
+    L = lib()
+    L.orc_quantize_e4m3.argtypes = [C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]
+    L.orc_quantize_e4m3.restype = None
+    L.orc_quantize_e4m3(_p(x), x.size, C.c_float(inv_scale), _p(y))
+    return y

@@ -245,3 +245,16 @@ def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
 def test_maxpool_bit_exact(eng, oracle, h, w):
     x = f16(np.random.default_rng(w).normal(0, 2, (2, h, w, 64)))
     assert np.array_equal(eng.op_maxpool(x), oracle.maxpool3x3s2(x))
+
+
+@pytest.mark.parametrize("inv_scale", [1.0, 0.37, 8.0, 1.0 / 448.0])
+def test_quantize_e4m3_every_f16_bit_exact(eng, oracle, inv_scale):
+    """f16 -> OCP FP8 E4M3 on the device (hardware conversion behind a clamp) against the oracle's encoder
+    for all 65 536 f16 bit patterns: nearest-even rounding, saturation at +-448, subnormals, zeros, NaN."""
+    bits = np.arange(65536, dtype=np.uint16)
+    got = eng.op_quantize_e4m3(bits, inv_scale)
+    x = bits.view(np.float16).astype(np.float32)
+    want = oracle.quantize_e4m3(x, inv_scale)
+    nan = np.isnan(x)
+    assert np.array_equal(got[~nan], want[~nan])
+    assert np.all((got[nan] & 0x7F) == 0x7F)

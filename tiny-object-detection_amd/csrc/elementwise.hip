@@ -119,6 +119,23 @@ __global__ __launch_bounds__(256) void cells_f32(const half_t* __restrict__ head
     out[t] = (float)heads[((long long)b * cells_img + cell) * ldh + 12 + c];
 }
 
+// f16 -> OCP FP8 E4M3 codes of x * inv_scale: round to nearest even, saturating at +-448 (groundwork for the
+// fp8 convolution path; semantics pinned by oracle/orc_fp8.c). The hardware conversion
+// (v_cvt_pk_fp8_f32) does the rounding; the clamp in front makes overflow saturate instead of turning
+// into NaN, and NaN inputs keep their sign with the NaN code.
+__global__ __launch_bounds__(256) void quantize_e4m3_f16(const half_t* __restrict__ x, uint8_t* __restrict__ y, long long n, float inv_scale) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float v = (float)x[t] * inv_scale;
+    uint8_t code;
+    if (v != v) code = (uint8_t)(((__float_as_uint(v) >> 24) & 0x80u) | 0x7Fu);
+    else {
+        const float c = fminf(fmaxf(v, -448.0f), 448.0f);
+        code = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.0f, 0, false) & 0xFF);
+    }
+    y[t] = code;
+}
+
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int Hp, int Wp, hipStream_t s) {
@@ -132,6 +149,10 @@ hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, 
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
                            long long xs, long long ys, hipStream_t s) {
     hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys);
+    return hipGetLastError();
+}
+hipError_t launch_quantize_e4m3(const half_t* x, uint8_t* y, long long n, float inv_scale, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_e4m3_f16, dim3(nblk(n)), dim3(256), 0, s, x, y, n, inv_scale);
     return hipGetLastError();
 }
 hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc, float* conf,

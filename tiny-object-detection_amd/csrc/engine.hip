@@ -1634,6 +1634,21 @@ int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S,
     return op_stem_pool_impl(h, nullptr, rgb, n, S, w, bias, stem_out, pool_out);
 }
 
+int yh_op_quantize_e4m3(yh_engine* h, const uint16_t* x, size_t n, float inv_scale, uint8_t* y) {
+    if (!h || !x || !y || n < 1) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    void *dx = nullptr, *dy = nullptr;
+    hipError_t e = hipMalloc(&dx, n * 2);
+    if (e == hipSuccess) e = hipMalloc(&dy, n);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, n * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_quantize_e4m3((const half_t*)dx, (uint8_t*)dy, (long long)n, inv_scale, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy, n, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("quantize op: ") + hipGetErrorString(e));
+    return YH_OK;
+}
+
 int yh_op_detect(yh_engine* h, const uint16_t* loc, const uint16_t* conf, const uint16_t* mask, const uint16_t* proto, int32_t n) {
     if (!h || !loc || !conf || !mask || !proto) return YH_EINVAL;
     if (n < 1 || n > h->cfg.max_batch) return h->fail(YH_EINVAL, "n out of range");

@@ -86,6 +86,7 @@ hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int 
 hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc,
                               float* conf, float* mask, hipStream_t s);
 hipError_t launch_f16_to_f32(const half_t* x, float* y, long long n, hipStream_t s);
+hipError_t launch_quantize_e4m3(const half_t* x, uint8_t* y, long long n, float inv_scale, hipStream_t s);
 hipError_t launch_cells_f32(const half_t* heads, int n, int cells_img, int cells_l0, int ldh, int C,
                             float* out, hipStream_t s);
 

@@ -87,6 +87,7 @@ SYMBOLS = [
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("yh_op_quantize_e4m3", _i, [_vp, _vp, _sz, C.c_float, _vp]),
     ("yh_op_conv2d_levels_f16", _i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -351,6 +352,13 @@ class Engine:
         self._chk(self.L.yh_op_stem_pool_rgb8(self.h, _p(rgb), n, S, _p(wb), _p(bias), _p(stem) if want_stem else None, _p(pool)))
         f = lambda a: a.view(np.float16).astype(np.float32)
         return (f(stem) if want_stem else None), f(pool)
+
+    def op_quantize_e4m3(self, x_f16_bits, inv_scale=1.0):
+        """x: uint16 array of f16 bit patterns -> uint8 e4m3 codes of x * inv_scale."""
+        xb = np.ascontiguousarray(x_f16_bits, np.uint16)
+        y = np.zeros(xb.shape, np.uint8)
+        self._chk(self.L.yh_op_quantize_e4m3(self.h, _p(xb), xb.size, C.c_float(inv_scale), _p(y)))
+        return y
 
     def op_detect(self, loc, conf, mask, proto):
         n = loc.shape[0]
