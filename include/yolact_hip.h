@@ -261,6 +261,13 @@ int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S,
 /* Groundwork for an fp8 convolution path (not used by the forward yet): y[i] = OCP FP8 E4M3 code of
  * x[i] * inv_scale (x: f16 bits), round to nearest even, saturating at +-448, NaN -> 0x7F | sign. */
 int yh_op_quantize_e4m3(yh_engine* h, const uint16_t* x, size_t n, float inv_scale, uint8_t* y);
+/* Experimental fp8 convolution (not used by the forward yet): x[n][hh][ww][cin] and w[cout][k][k][cin] are E4M3
+ * codes (cin % 128 == 0), f32 accumulation on the block-scaled MFMA with unit block scales,
+ * y = act(acc * scale[ch] + bias[ch] + residual) rounded to f16. If reps > 0, *ms_per_launch receives the mean
+ * kernel time of `reps` further launches. */
+int yh_op_conv2d_fp8(yh_engine* h, const uint8_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint8_t* w,
+                     const float* scale, const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                     const uint16_t* residual, int32_t act, uint16_t* y, int32_t reps, float* ms_per_launch);
 /* Detection tail alone on caller-provided head outputs (host f16 bits, layouts as outputs 0..3)
  * for n frames; results are then read with yh_read_detections. Lets the tail be checked
  * bit-for-bit against the oracle on identical inputs. */

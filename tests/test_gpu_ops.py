@@ -258,3 +258,30 @@ def test_quantize_e4m3_every_f16_bit_exact(eng, oracle, inv_scale):
     nan = np.isnan(x)
     assert np.array_equal(got[~nan], want[~nan])
     assert np.all((got[nan] & 0x7F) == 0x7F)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res", [
+    (2, 13, 11, 128, 256, 3, 1, 1, True),      # ragged M, images straddling tiles, borders
+    (1, 16, 16, 256, 512, 1, 1, 0, False),     # two channel tiles, two K steps
+    (3, 9, 9, 128, 200, 3, 2, 1, False),       # stride 2, channel tail (cout not a multiple of 8 * 32)
+])
+def test_conv_fp8_exact_on_integers(eng, oracle, n, h, w, cin, cout, k, stride, pad, res):
+    """Experimental fp8 convolution (E4M3 operands on the block-scaled MFMA, f32 accumulate): with
+    small-integer operands every product and sum is exact, so the result must equal the oracle's
+    convolution of the DECODED operands, scaled per channel (powers of two), bit for bit."""
+    rng = np.random.default_rng(cin + cout + k)
+    xi = rng.integers(-4, 5, (n, h, w, cin)).astype(np.float32)
+    wi = rng.integers(-3, 4, (cout, k, k, cin)).astype(np.float32)
+    xc, wc = oracle.quantize_e4m3(xi), oracle.quantize_e4m3(wi)
+    table = oracle.e4m3_decode_table()
+    assert np.array_equal(table[xc], xi) and np.array_equal(table[wc], wi)          # the codes carry the integers exactly
+    scale = (2.0 ** rng.integers(-3, 1, cout)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = rng.integers(-5, 6, (n, ho, wo, cout)).astype(np.float32) if res else None
+    y, _ = eng.op_conv2d_fp8(xc, wc, scale, b, stride, pad, r, 1)
+    acc = oracle.conv2d(xi, wi, np.zeros(cout, np.float32), stride, pad, None, 0, f16=False)
+    want = acc * scale + b
+    if res: want = want + r
+    want = np.maximum(want, 0).astype(np.float16).astype(np.float32)
+    assert np.array_equal(y, want)

@@ -55,7 +55,7 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 //      lane); 16: v_mfma_f32_16x16x32_f16 (K = 32, 4 accumulators per lane: lane l holds output
 //      pixel l & 15 and channels 4 (l >> 4) .. + 3). Same FLOPs per cycle; on real data the chip
 //      holds a higher clock on the 16x16x32 shape (guide: DVFS give-back item 7).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false>
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
@@ -238,7 +238,50 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         }
     }
 
-    if (STAGES == 2) {
+    if constexpr (STAGES == 2 && FP8) {
+        // fp8 (OCP E4M3) operands, block-scaled MFMA with unit scales: a 128-byte LDS row is 128 channels, one
+        // v_mfma_scale_f32_16x16x128_f8f6f4 consumes it whole (lane group g = lane >> 4 feeds bytes
+        // 32 g .. 32 g + 31 of its row for A and for B alike: the instruction pairs equal (g, byte)).
+        // A fragments are read in two halves so that 8 + 4 operand tiles of 8 VGPRs do not all live at once.
+        static_assert(MT == 16 && !SMALLC && !SPLITK && TC % 2 == 0, "fp8 form: 16x16x128, ordinary channels");
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        auto read_op = [&](const char* row) {
+            const u32x4 lo = *(const u32x4*)(row + (((2 * lh) ^ swz) << 4)), hi = *(const u32x4*)(row + (((2 * lh + 1) ^ swz) << 4));
+            v8i v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (int)lo[e]; v[4 + e] = (int)hi[e]; }
+            return v;
+        };
+        load_tile(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk_total; ++kt) {
+            const bool more = kt + 1 < nk_total;
+            const char* base = lds + cur * AB_BYTES;
+            if (more) tile_begin();
+            v8i b[TMT];
+#pragma unroll
+            for (int j = 0; j < TMT; ++j) b[j] = read_op(base + b_row + j * TSTR);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                v8i a[TC / 2];
+#pragma unroll
+                for (int i = 0; i < TC / 2; ++i) a[i] = read_op(base + a_row + (hh * (TC / 2) + i) * TSTR);
+                if (more) {
+#pragma unroll
+                    for (int d = (hh * NDMA) / 2; d < ((hh + 1) * NDMA) / 2; ++d) tile_part(cur ^ 1, d);
+                }
+#pragma unroll
+                for (int i = 0; i < TC / 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j)
+                        acc[hh * (TC / 2) + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[hh * (TC / 2) + i][j], 0, 0, 0, 127, 0, 127);
+            }
+            if (more) tile_end();
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else if (STAGES == 2) {
         // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
         // step k, between that slice's fragment reads and its MFMAs: DMA issue (the expensive
         // part of LDS-DMA for the issuing wave) overlaps MFMA execution instead of preceding it.
@@ -353,6 +396,12 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    float scale8[FP8 ? 8 : 1];
+    if (FP8) {
+        const f32x4 s0 = *(const f32x4*)(p.scale + ch), s1 = *(const f32x4*)(p.scale + ch + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { scale8[e] = s0[e]; scale8[4 + e] = s1[e]; }
+    }
 #pragma unroll
     for (int h = 0; h < EPI; ++h) {
         // multi-round epilogues: the residual rows of this round are requested up front (one latency)
@@ -404,7 +453,10 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        if (FP8) { v[e] = v0[e] * scale8[e] + bias8[e]; v[4 + e] = v1[e] * scale8[4 + e] + bias8[4 + e]; }
+                        else { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+                    }
                     long long yo, ro;
                     offsets(m, yo, ro);
                     if (p.res) {
@@ -624,7 +676,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 
 int conv_tile_ch(ConvTile t) {
     switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
-                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: return 256; }
+                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
@@ -645,6 +697,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
         case TILE_64x64_S3: return "conv_igemm_f16<64,64,2,2,0,3>";
+        case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
     }
     return "?";
@@ -709,6 +762,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2>), grid, dim3(512), 0, stream, p); break;
+        case TILE_256x256_FP8:
+            if (!p.scale) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, true>), grid, dim3(512), 0, stream, p);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1634,6 +1634,68 @@ int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S,
     return op_stem_pool_impl(h, nullptr, rgb, n, S, w, bias, stem_out, pool_out);
 }
 
+// Experimental: the fp8 form of the convolution through the 256x256 tile. x: E4M3 codes
+// [n][hh][ww][cin], w: E4M3 codes [cout][k][k][cin], out = act(acc * scale[ch] + bias[ch] (+ residual)) as f16.
+int yh_op_conv2d_fp8(yh_engine* h, const uint8_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint8_t* w,
+                     const float* scale, const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                     const uint16_t* residual, int32_t act, uint16_t* y, int32_t reps, float* ms_per_launch) {
+    if (!h || !x || !w || !scale || !bias || !y || n < 1 || k < 1 || stride < 1 || cin % 128 != 0 || (act < 0 || act > 1))
+        return h ? h->fail(YH_EINVAL, "fp8 conv op: need cin % 128 == 0") : YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int P = out_dim(hh, k, stride, pad), Q = out_dim(ww, k, stride, pad);
+    if (P < 1 || Q < 1) return h->fail(YH_EINVAL, "fp8 conv op: empty output");
+    const int Kpad = k * k * cin, coutPad = round_up(cout, 256), cout8 = round_up(cout, 8);
+    const size_t M = (size_t)n * P * Q, xbytes = (size_t)n * hh * ww * cin;
+    std::vector<uint8_t> wp((size_t)coutPad * Kpad, 0);
+    memcpy(wp.data(), w, (size_t)cout * Kpad);                       // [cout][k][k][cin] is already the panel's K order
+    std::vector<float> bp(coutPad, 0.0f), sp(coutPad, 0.0f);
+    memcpy(bp.data(), bias, (size_t)cout * 4); memcpy(sp.data(), scale, (size_t)cout * 4);
+    std::vector<uint16_t> rs, ys(M * cout8);
+    if (residual) { rs.assign(M * cout8, 0); for (size_t m = 0; m < M; ++m) memcpy(&rs[m * cout8], &residual[m * cout], (size_t)cout * 2); }
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *dsc = nullptr, *dy = nullptr, *dr = nullptr;
+    const size_t zero_off = (xbytes + 15) & ~(size_t)15;
+    hipError_t e = hipMalloc(&dx, zero_off + 64);
+    if (e == hipSuccess) e = hipMemset(dx, 0, zero_off + 64);
+    if (e == hipSuccess) e = hipMalloc(&dw, wp.size());
+    if (e == hipSuccess) e = hipMalloc(&db, bp.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&dsc, sp.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&dy, ys.size() * 2);
+    if (e == hipSuccess && residual) e = hipMalloc(&dr, rs.size() * 2);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, xbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dw, wp.data(), wp.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dsc, sp.data(), sp.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && residual) e = hipMemcpy(dr, rs.data(), rs.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dy, 0xFF, ys.size() * 2);
+    if (e == hipSuccess) {
+        ConvParams p;
+        memset(&p, 0, sizeof p);
+        p.x = (const half_t*)dx; p.w = (const half_t*)dw; p.bias = (const float*)db; p.scale = (const float*)dsc;
+        p.res = (const half_t*)dr; p.y = (half_t*)dy;
+        // the loader's units are 2 bytes: two fp8 values
+        p.x_img_stride = (long long)hh * ww * (cin / 2); p.y_img_stride = (long long)P * Q * cout8; p.res_img_stride = p.y_img_stride;
+        p.x_zero_off = (unsigned)zero_off; p.x_bytes = p.x_zero_off + 16u; p.w_bytes = (unsigned)wp.size();
+        p.N = n; p.H = hh; p.W = ww; p.C = cin / 2; p.P = P; p.Q = Q; p.R = k; p.S = k; p.stride = stride; p.pad = pad;
+        p.M = (int)M; p.cout8 = cout8; p.ldw = Kpad / 2; p.ksteps = Kpad / 128; p.ldy = cout8; p.ldres = cout8; p.y_dense = 1;
+        p.act = act; p.tanh_from = INT_MAX; p.n_ch_tiles = coutPad / 256; p.k_slices = 1;
+        e = launch_conv(p, TILE_256x256_FP8, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess && reps > 0 && ms_per_launch) {          // timing: reps back-to-back launches between two events
+            hipEventRecord(h->ev0, h->stream);
+            for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_conv(p, TILE_256x256_FP8, h->stream);
+            hipEventRecord(h->ev1, h->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+            float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            *ms_per_launch = ms / reps;
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpy(ys.data(), dy, ys.size() * 2, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dw); hipFree(db); hipFree(dsc); hipFree(dy); if (dr) hipFree(dr);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("fp8 conv op: ") + hipGetErrorString(e));
+    for (size_t m = 0; m < M; ++m) memcpy(&y[m * cout], &ys[m * cout8], (size_t)cout * 2);
+    return YH_OK;
+}
+
 int yh_op_quantize_e4m3(yh_engine* h, const uint16_t* x, size_t n, float inv_scale, uint8_t* y) {
     if (!h || !x || !y || n < 1) return YH_EINVAL;
     HIPCHK(h, hipSetDevice(h->dev));

@@ -38,6 +38,9 @@ struct ConvParams {
     // multi-level input (nlev > 0): the P*Q rows of an image are the cells of nlev pyramid levels laid end to
     // end (level l: rows lev_start[l].., a lev_h[l] x lev_w[l] image); taps stay inside their level
     int nlev, lev_start[5], lev_h[5], lev_w[5];
+    // fp8 form (experimental): x and w hold OCP E4M3 bytes; C, ldw and the image strides are in
+    // 2-byte units (two fp8 values), so the loader is the f16 one; out = acc * scale[ch] + bias
+    const float* scale;
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
@@ -54,7 +57,7 @@ struct ConvParams {
 
 // (ids 4 and 9-11 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel - DESIGN.md §4)
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8,
-                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17 };
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17, TILE_256x256_FP8 = 20 };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);

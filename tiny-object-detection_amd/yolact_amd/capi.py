@@ -88,6 +88,7 @@ SYMBOLS = [
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_quantize_e4m3", _i, [_vp, _vp, _sz, C.c_float, _vp]),
+    ("yh_op_conv2d_fp8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     ("yh_op_conv2d_levels_f16", _i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -352,6 +353,20 @@ class Engine:
         self._chk(self.L.yh_op_stem_pool_rgb8(self.h, _p(rgb), n, S, _p(wb), _p(bias), _p(stem) if want_stem else None, _p(pool)))
         f = lambda a: a.view(np.float16).astype(np.float32)
         return (f(stem) if want_stem else None), f(pool)
+
+    def op_conv2d_fp8(self, x_codes, w_codes, scale, bias, stride=1, pad=0, residual=None, act=0, reps=0):
+        """x_codes [n][h][w][cin] / w_codes [cout][k][k][cin]: uint8 E4M3 codes -> (y f32 NHWC, ms per launch or None)."""
+        n, hh, ww, cin = x_codes.shape
+        cout, k = w_codes.shape[0], w_codes.shape[1]
+        ho, wo = (hh + 2 * pad - k) // stride + 1, (ww + 2 * pad - k) // stride + 1
+        xc, wc = np.ascontiguousarray(x_codes, np.uint8), np.ascontiguousarray(w_codes, np.uint8)
+        sc, bs = np.ascontiguousarray(scale, np.float32), np.ascontiguousarray(bias, np.float32)
+        rb = _f16_bits(residual) if residual is not None else None
+        y = np.zeros((n, ho, wo, cout), np.uint16)
+        ms = C.c_float(0)
+        self._chk(self.L.yh_op_conv2d_fp8(self.h, _p(xc), n, hh, ww, cin, _p(wc), _p(sc), _p(bs), cout, k, stride, pad,
+                                          _p(rb) if rb is not None else None, act, _p(y), reps, C.byref(ms) if reps else None))
+        return y.view(np.float16).astype(np.float32), (ms.value if reps else None)
 
     def op_quantize_e4m3(self, x_f16_bits, inv_scale=1.0):
         """x: uint16 array of f16 bit patterns -> uint8 e4m3 codes of x * inv_scale."""
