@@ -41,3 +41,23 @@ def test_graft_entry_smoke_runs(built):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_two_rank_control_flow_on_one_gpu(built):
+    """The N > 1 path of bench.py (barriers, MAX over ranks, rank-0-only extras, weight broadcast) with two
+    ranks sharing cuda:0 over gloo (--rehearse-on-one-gpu): a control-flow rehearsal, not a measurement.
+    The real N = 2/4/8 runs use RCCL with one rank per GPU and are the driver's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--rehearse-on-one-gpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["global_batch"] == 8 and "cpu_baseline" not in b
+    assert abs(b["value"] - 2 * 4 * 3 / (b["ms_per_step"] * 3e-3)) < 0.01 * b["value"]
