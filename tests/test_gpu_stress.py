@@ -94,3 +94,36 @@ def test_stem_pool_random_sizes(eng, oracle):
         stem, pool = eng.op_stem_pool(x, wt, b)
         so = oracle.conv2d(x, wt, b, 2, 3, None, 1, f16=True)
         assert np.array_equal(stem, so) and np.array_equal(pool, oracle.maxpool3x3s2(so)), (n, S)
+
+
+@pytest.mark.parametrize("S,C,top_k,max_dets", [(96, 81, 8, 5), (96, 21, 50, 100), (320, 81, 200, 100), (320, 81, 37, 11)])
+def test_tail_random_heads_bit_exact(built, oracle, S, C, top_k, max_dets):
+    """Seeded random head tensors through yh_op_detect against the oracle, bit for bit: candidate counts from
+    zero to every prior of a class (more than the 4 096 keys the class kernel stages in LDS at S = 320:
+    the unstaged radix-select path), exact score ties, top_k and max_dets that are not powers of two."""
+    import yolact_amd as ya
+    eng = ya.Engine(input_size=S, max_batch=2, use_graph=False, num_classes=C, top_k=top_k, max_dets=max_dets)
+    P, hp = eng.P, eng.hp
+    pri = eng.priors()
+    rng = np.random.default_rng(S + C + top_k)
+    h = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    for trial in range(3):
+        loc = h(rng.normal(0, 0.5, (2, P, 4)))
+        conf = rng.normal(0, 1.5, (2, P, C))
+        conf[:, :, 0] += 4.0
+        hot = int(rng.integers(1, C))
+        if trial == 0:
+            conf[0, :, hot] = 9.0                                   # every prior a candidate of one class, all tied
+        elif trial == 1:
+            conf[0, :, hot] += rng.normal(6.0, 0.3, P)              # every prior a candidate, distinct scores
+            conf[1] = -5.0; conf[1, :, 0] = 5.0                     # frame 1: no candidate at all
+        conf = h(conf)
+        mask = h(np.tanh(rng.normal(0, 1, (2, P, 32))))
+        proto = h(np.maximum(rng.normal(0, 1, (2, hp, hp, 32)), 0))
+        eng.op_detect(loc, conf, mask, proto)
+        for f in range(2):
+            d, m = eng.detections(f)
+            od, om = oracle.detect(loc[f], conf[f], mask[f], proto[f], pri, num_classes=C, top_k=top_k, max_dets=max_dets)
+            assert [(x["class_id"], x["prior"], x["score"], x["box"]) for x in d] == [(x["class_id"], x["prior"], x["score"], x["box"]) for x in od], (trial, f)
+            assert np.array_equal(m, om), (trial, f)
+    eng.close()
