@@ -168,3 +168,26 @@ def test_yolact_init_from_model_file(built, oracle, tmp_path, golden_dir):
     with pytest.raises(FileNotFoundError):
         ya.Yolact.init(model_path=str(tmp_path / "missing.tflite"))
     y.interpreter.close()
+
+
+def test_conv_random_geometries_bit_exact(built):
+    """Seeded sweep over CONV_2D / DEPTHWISE_CONV_2D geometries: input channels that take the dot-product
+    kernel with the K split over waves (Ci % 16 == 0), without it (Ci % 4 == 0) and the scalar kernel
+    (other Ci), output channels around the 8-wide channel block, kernel 1/3/5, stride 1/2, SAME / VALID,
+    every fused activation - each against the numpy oracle, bit for bit."""
+    rng = np.random.default_rng(99)
+    for _ in range(60):
+        code = "CONV_2D" if rng.random() < 0.75 else "DEPTHWISE_CONV_2D"
+        k, stride = int(rng.choice([1, 3, 5])), int(rng.choice([1, 2]))
+        h, w = int(rng.integers(k, 20)), int(rng.integers(k, 20))
+        kw = dict(k=k, stride=stride, padding=int(rng.integers(0, 2)), act=int(rng.choice([0, 1, 3])), h=h, w=w,
+                  ci=int(rng.choice([3, 4, 8, 12, 16, 32, 48, 64, 96])), co=int(rng.choice([1, 5, 8, 9, 16, 24, 31, 64])),
+                  so=float(rng.uniform(0.02, 0.3)))
+        if code == "DEPTHWISE_CONV_2D":
+            kw["dm"] = int(rng.choice([1, 1, 2]))
+        model = M.single_op(code, rng, **kw)
+        t_in = model.tensors[model.inputs[0]]
+        x = rng.integers(0, 256, t_in.shape, dtype=np.uint8)
+        eng, val, outs = _run_both(model, x)
+        assert np.array_equal(outs[0], val[model.outputs[0]]), (code, kw)
+        eng.close()
