@@ -212,7 +212,11 @@ class Net:
     def flops_per_frame(self):
         return lib().orc_net_flops_per_frame(self.h)
 
-    def forward(self, rgb, f16=True, nthreads=None):
+    def forward(self, rgb, f16=True, nthreads=None, fp8_study=False):
+        """fp8_study: the K-heavy 3x3 convs run on E4M3-rounded operands (accuracy study)."""
+        lib().orc_net_set_fp8_study.argtypes = [C.c_void_p, C.c_int]
+        lib().orc_net_set_fp8_study.restype = None
+        lib().orc_net_set_fp8_study(self.h, int(fp8_study))   # 0 off, 1 per-tensor / per-channel scales, 2 MX blocks of 32
         rgb = np.ascontiguousarray(rgb, np.uint8)
         n = rgb.shape[0]
         assert rgb.shape == (n, self.S, self.S, 3)

@@ -74,6 +74,7 @@ struct orc_net {
     float* priors;
     double flops;
     int nthreads, f16;
+    int fp8;   /* accuracy study: fake-quantise the K-heavy 3x3 convs' operands to E4M3 */
 };
 
 /* ------------------------------------------------------------------ canonical conv table */
@@ -322,6 +323,48 @@ static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x
     if (cw->cin != x->c) { fprintf(stderr, "oracle: conv %s cin %d vs %d\n", name, cw->cin, x->c); abort(); }
     int ho = out_dim(x->h, cw->kh, stride, pad), wo = out_dim(x->w, cw->kw, stride, pad);
     tensor* y = new_t(net, name, x->n, ho, wo, cw->cout);
+    /* study modes: 1 per-tensor / per-channel scales, 2 MX blocks, 3 = mode 1 on the protonet only */
+    if (net->fp8 && cw->kh == 3 && cw->cin % 128 == 0 && cw->cin >= 256 && (net->fp8 != 3 || strncmp(name, "proto", 5) == 0)) {
+        /* fp8 study: operands rounded to E4M3 - activations with one scale per tensor (max |x| -> 448),
+         * weights with one per output channel - products and sums stay f32. What an fp8 engine path with
+         * per-tensor activation scales and per-channel weight scales would compute, up to summation order. */
+        size_t nx = (size_t)x->n * x->h * x->w * x->c, K = (size_t)cw->kh * cw->kw * cw->cin;
+        float* xq = (float*)malloc(nx * sizeof(float));
+        float* wq = (float*)malloc(K * cw->cout * sizeof(float));
+        if (net->fp8 == 2) {
+            /* MX form: one power-of-two (E8M0) scale per 32 consecutive channels - of every pixel for the
+             * activations, of every (tap, output channel) for the weights - the block scaling the
+             * v_mfma_scale_* instructions apply in hardware */
+            for (size_t i0 = 0; i0 < nx; i0 += 32) {
+                float a = 0.0f;
+                for (int e = 0; e < 32; ++e) { float v = fabsf(x->d[i0 + e]); if (v > a) a = v; }
+                const float sb = a > 0.0f ? exp2f(ceilf(log2f(a / 448.0f))) : 1.0f;
+                for (int e = 0; e < 32; ++e) xq[i0 + e] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i0 + e] / sb)) * sb;
+            }
+            for (int o = 0; o < cw->cout; ++o)
+                for (size_t k0 = 0; k0 < K; k0 += 32) {
+                    float a = 0.0f;
+                    for (int e = 0; e < 32; ++e) { float v = fabsf(cw->wt[(k0 + e) * cw->cout + o]); if (v > a) a = v; }
+                    const float sb = a > 0.0f ? exp2f(ceilf(log2f(a / 448.0f))) : 1.0f;
+                    for (int e = 0; e < 32; ++e) wq[(k0 + e) * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[(k0 + e) * cw->cout + o] / sb)) * sb;
+                }
+        } else {
+        float ax = 0.0f;
+        for (size_t i = 0; i < nx; ++i) { float a = fabsf(x->d[i]); if (a > ax) ax = a; }
+        const float sx = ax > 0.0f ? ax / 448.0f : 1.0f;
+        for (size_t i = 0; i < nx; ++i) xq[i] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i] / sx)) * sx;
+        for (int o = 0; o < cw->cout; ++o) {
+            float aw = 0.0f;
+            for (size_t k = 0; k < K; ++k) { float a = fabsf(cw->wt[k * cw->cout + o]); if (a > aw) aw = a; }
+            const float sw = aw > 0.0f ? aw / 448.0f : 1.0f;
+            for (size_t k = 0; k < K; ++k) wq[k * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[k * cw->cout + o] / sw)) * sw;
+        }
+        }
+        conv_core(xq, x->n, x->h, x->w, x->c, wq, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
+                  res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo);
+        free(xq); free(wq);
+        return y;
+    }
     conv_core(x->d, x->n, x->h, x->w, x->c, cw->wt, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
               res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo);
     return y;
@@ -399,6 +442,7 @@ void orc_net_destroy(orc_net* net) {
     free(net);
 }
 
+void orc_net_set_fp8_study(orc_net* net, int on) { net->fp8 = on; }
 int orc_net_num_priors(const orc_net* net) { return net->P; }
 void orc_net_proto_dims(const orc_net* net, int* hp, int* wp) { *hp = net->hp; *wp = net->wp; }
 void orc_net_priors(const orc_net* net, float* out) { memcpy(out, net->priors, (size_t)net->P * 16); }

@@ -49,3 +49,21 @@ def test_round_trip_and_scale(oracle):
     assert np.array_equal(oracle.e4m3_decode_table()[codes], t[fin])          # decode(encode(v)) == v for every finite code
     x = np.array([1.0, 3.0, 100.0, -0.3], np.float32)
     assert np.array_equal(oracle.quantize_e4m3(x, 0.5), oracle.quantize_e4m3(x * np.float32(0.5)))
+
+
+def test_fp8_study_modes_of_the_net_forward(oracle):
+    """The oracle's fp8 accuracy study: E4M3-rounded operands on the K-heavy 3x3 convs move the
+    heads by a few per cent and nothing else; the protonet-only mode leaves the prediction heads untouched."""
+    S = 128
+    net = oracle.Net(50, S, 81, seed=1)
+    x = np.random.default_rng(0).integers(0, 256, (1, S, S, 3), dtype=np.uint8)
+    ref = net.forward(x, f16=True)
+    rel = lambda u, v: float(np.sqrt(((u - v) ** 2).mean()) / np.sqrt((u ** 2).mean()))
+    for mode in (1, 2):
+        got = net.forward(x, f16=True, fp8_study=mode)
+        errs = [rel(u, v) for u, v in zip(ref, got)]
+        assert all(0.005 < e < 0.25 for e in errs), (mode, errs)
+    got = net.forward(x, f16=True, fp8_study=3)
+    assert all(np.array_equal(u, v) for u, v in zip(ref[:3], got[:3])) and 0.005 < rel(ref[3], got[3]) < 0.25
+    again = net.forward(x, f16=True)
+    assert all(np.array_equal(u, v) for u, v in zip(ref, again))          # the switch does not stick
