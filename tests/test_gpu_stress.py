@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 TILES = {0: "128x128", 1: "64x256", 2: "32x256", 5: "128x256", 7: "128x128_S3", 8: "256x256_M16", 12: "128x128_M16",
-         13: "128x128_S3_M16", 15: "128x256_M16", 16: "64x64_S3"}
+         13: "128x128_S3_M16", 15: "128x256_M16", 16: "64x64_S3", 21: "128x128_K1", 22: "64x256_K1"}
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +43,7 @@ def test_conv_random_shapes_and_tiles(eng, oracle):
         n, h, w = int(rng.integers(1, 4)), int(rng.integers(k, 24)), int(rng.integers(k, 24))
         cin = int(rng.choice([64, 128, 192])); cout = int(rng.choice([8, 24, 64, 72, 128, 200, 256, 351, 512]))
         tile = int(rng.choice(list(TILES)))
-        if (tile == 1 and cout > 64) or (tile == 2 and cout > 32):
+        if (tile in (1, 22) and cout > 64) or (tile == 2 and cout > 32):
             tile = 0
         res, act = bool(rng.integers(0, 2)), int(rng.integers(0, 2))
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1

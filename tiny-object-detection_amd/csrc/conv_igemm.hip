@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     constexpr int LDS_BYTES = cmax<RING_BYTES, (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
     static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
-    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && !SMALLC), "ring variants: no ordinary loads may share the loop");
+    static_assert(STAGES == 1 || STAGES == 2 || ((STAGES == 3 || STAGES == 4) && !SMALLC), "ring variants: no ordinary loads may share the loop");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -281,6 +281,29 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             __syncthreads();
             cur ^= 1;
         }
+    } else if (STAGES == 1) {
+        // One LDS stage, no overlap inside the workgroup: for the HBM-bound 1x1 layers (K <= 256, one to
+        // four steps) what hides latency is the number of workgroups per CU, and 34 KB of LDS (with the
+        // split epilogue) lets four of them live on a CU instead of two.
+        for (int kt = 0; kt < nk_total; ++kt) {
+            if (kt) __syncthreads();   // every wave is done reading the previous tile
+            load_tile(0);
+            __syncthreads();           // vmcnt(0) + barrier: the tile has landed and is visible
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int co = ((KG * kk + lh) ^ swz) << 4;
+                half8 a[TC], b[TMT];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) a[i] = *(const half8*)(lds + a_row + i * TSTR + co);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) b[j] = *(const half8*)(lds + b_row + j * TSTR + co);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j) acc[i][j] = mfma_f16<MT>(a[i], b[j], acc[i][j]);
+            }
+        }
+        __syncthreads();  // LDS is reused by the epilogue
     } else if (STAGES == 2) {
         // Double buffer. The DMA of step k+1 is issued in four slices, one per 16-wide k-slice of
         // step k, between that slice's fragment reads and its MFMAs: DMA issue (the expensive
@@ -675,12 +698,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
                  case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -697,6 +720,8 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
         case TILE_64x64_S3: return "conv_igemm_f16<64,64,2,2,0,3>";
+        case TILE_128x128_K1: return "conv_igemm_f16<128,128,2,2,0,1>";
+        case TILE_64x256_K1: return "conv_igemm_f16<64,256,1,4,0,1>";
         case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
     }
@@ -749,6 +774,8 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
     switch (tile) {
         case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
+        case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2>), grid, dim3(256), 0, stream, p); break;
+        case TILE_64x256_K1: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 1, 2>), grid, dim3(256), 0, stream, p); break;
         case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true, 2, 1>), grid, dim3(256), 0, stream, p); break;
