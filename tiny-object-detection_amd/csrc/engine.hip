@@ -565,12 +565,15 @@ ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml) {
     // HBM-bound 1x1 layers (K <= 512): the single-stage "streaming" forms keep 34-40 KB of LDS per workgroup,
     // so four workgroups share a CU instead of two and their load and store phases overlap each other
     // (4.0 -> 5.2 TB/s on the 69 x 69 expand convs at batch 64). A/B switch: YH_K1TILE=0.
-    static const int k1 = getenv("YH_K1TILE") ? atoi(getenv("YH_K1TILE")) : 2;   // 1: 128x128 form only, 2: also the 64-channel form
+    static const int k1 = getenv("YH_K1TILE") ? atoi(getenv("YH_K1TILE")) : 3;   // 1: 128x128 form only, 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3
     static const int k1_maxk = getenv("YH_K1_MAXK") ? atoi(getenv("YH_K1_MAXK")) : 512;
     if (k1 && !ml && pn.k == 1 && pn.Kpad <= k1_maxk) {
         if (pn.coutPad % 128 == 0 && pn.cout > 64 && (long long)((M + 127) / 128) * (pn.coutPad / 128) >= 1024) return TILE_128x128_K1;
         if (k1 >= 2 && pn.tile == TILE_64x256 && (M + 255) / 256 >= 1024) return TILE_64x256_K1;
     }
+    // (the 64-channel 3x3 convs of layer 1 too: 590 -> 715 TFLOP/s - their LDS fill per MFMA is what binds them, and
+    // four co-resident workgroups overlap it better than a double buffer inside two)
+    if (k1 >= 3 && !ml && pn.k == 3 && pn.tile == TILE_64x256 && (M + 255) / 256 >= 1024) return TILE_64x256_K1;
     if (pn.tile == TILE_128x128 && pn.Kpad >= 256) {
         const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
         if (b128 <= 256) return TILE_128x128_S3;
