@@ -531,6 +531,9 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) {
     __shared__ __attribute__((aligned(16))) char patch[SP_PR * SP_PC * 8];
     __shared__ __attribute__((aligned(16))) char stage[SP_NPX * SP_SS];
+    // fused preprocessing: (v - mean) / std rounded to f16, tabulated once per workgroup for the 256 byte values
+    // of each channel with the preprocess kernel's own expression (six divisions per fetched chunk otherwise)
+    __shared__ half_t norm_lut[3 * 256];
     typedef float accv __attribute__((ext_vector_type(4)));
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lh = lane >> 4;
@@ -545,6 +548,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) bias4[ct] = *(const f32x4*)(p.bias + (ct0 + ct) * 16 + 4 * lh);
 
+    if (p.rgb) {
+        const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
+        for (int e = tid; e < 3 * 256; e += 512) norm_lut[e] = (half_t)(((float)(e & 255) - mean[e >> 8]) / sd[e >> 8]);
+        __syncthreads();
+    }
     const int tiles_img = p.tiles_y * p.tiles_x, total = p.n * tiles_img;
     constexpr int NCH = SP_PR * (SP_PC / 2), NLD = (NCH + 511) / 512;   // 16-byte patch chunks, per-thread slots
     half8 nv[NLD];
@@ -563,14 +571,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
             if (p.rgb) {   // fused preprocessing: two pixels of raw RGB -> (v - mean) / std in f16, zero outside the image
                 const int iy = gy - 3;
                 if (i < NCH && (unsigned)iy < (unsigned)p.S) {
-                    const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
                     const uint8_t* row = p.rgb + ((long long)b * p.S + iy) * p.S * 3;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
                         const int ix = gx + px - 3;
                         if ((unsigned)ix < (unsigned)p.S) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) nv[k][px * 4 + c] = (half_t)(((float)row[ix * 3 + c] - mean[c]) / sd[c]);
+                            for (int c = 0; c < 3; ++c) nv[k][px * 4 + c] = norm_lut[c * 256 + row[ix * 3 + c]];
                         }
                     }
                 }
