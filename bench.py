@@ -150,8 +150,13 @@ def host_to_detections_latency(eng, host_frames, reps=100):
 
 
 def accuracy_vs_oracle(eng_out, orc_out):
-    """Engine vs CPU oracle on the same frame and weights (the restated acceptance target of SURVEY.md
-    §8c; NOT parity with CPU tflite): detections matched by (class, prior); mask IoU over matched pairs."""
+    """Engine vs CPU oracle on the same frame and weights (the restated acceptance target of SURVEY.md §8c; NOT
+    parity with CPU tflite). Order-insensitive and over ALL detections of both sides:
+      mask_iou_all  per class, the union of the engine's masks against the union of the oracle's masks,
+                    intersections and unions summed over the classes either side detected - a detection only one
+                    side has counts against it with every pixel of its mask;
+      matched / unmatched_*  detections paired by (class, prior);
+      mask_iou_matched  the survivor statistic round 1 reported (matched pairs only), kept for comparison."""
     import numpy as np
     (ed, em), (od, om) = eng_out, orc_out
     ek = {(d["class_id"], d["prior"]): i for i, d in enumerate(ed)}
@@ -163,7 +168,20 @@ def accuracy_vs_oracle(eng_out, orc_out):
         matched += 1
         a, b = em[i] > 0, om[j] > 0
         inter += int(np.logical_and(a, b).sum()); union += int(np.logical_or(a, b).sum())
+    ia = ua = 0
+    shape = em.shape[1:] if len(ed) else om.shape[1:]
+    for c in sorted({d["class_id"] for d in ed} | {d["class_id"] for d in od}):
+        ue, uo = np.zeros(shape, bool), np.zeros(shape, bool)
+        for i, d in enumerate(ed):
+            if d["class_id"] == c:
+                ue |= em[i] > 0
+        for j, d in enumerate(od):
+            if d["class_id"] == c:
+                uo |= om[j] > 0
+        ia += int((ue & uo).sum()); ua += int((ue | uo).sum())
     return dict(oracle_dets=len(od), engine_dets=len(ed), matched_class_and_prior=matched,
+                unmatched_oracle=len(od) - matched, unmatched_engine=len(ed) - matched,
+                mask_iou_all=round(ia / ua, 5) if ua else None,
                 mask_iou_matched=round(inter / union, 5) if union else None)
 
 

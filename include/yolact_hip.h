@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 1
+#define YH_ABI_VERSION 2
 
 enum {
     YH_OK = 0,
@@ -51,6 +51,46 @@ enum {
 
 typedef struct yh_engine yh_engine; /* opaque; replaces struct Yolact<'a> (src/yolact.rs:13-15) */
 
+/* Arithmetic of the K-heavy convolutions. F16: f16 operands everywhere (configs[1]-[3]).
+ * FP8: 3x3 convolutions with >= 256 input channels read OCP E4M3 activations (written by the producing layer's
+ * epilogue, one calibrated scale per tensor) and E4M3 weights (one scale per output channel) on the block-scaled
+ * fp8 MFMA; everything else stays f16 (configs[4]; the reference's own model is quantised end to end,
+ * data/README.md:5-10, data/FRC_model_edgetpu.log:7-19). */
+enum { YH_PRECISION_F16 = 0, YH_PRECISION_FP8 = 1 };
+
+/* Measurement and test knobs of ONE handle. Every field: -1 = the library's default.
+ * None of them changes results beyond the stated f16 tolerance (most are bit-equivalent); they exist so that
+ * every launch-plan decision can be re-measured A/B and so that tests can reach every plan with small tensors.
+ * There are no process-global switches: the library reads no environment variable. */
+typedef struct yh_tuning {
+    int32_t plan_cus;        /* CU count the launch plans assume (default: the device's multiProcessorCount) */
+    int32_t mfma16;          /* 256x256 tile on v_mfma_f32_16x16x32_f16 (1, default) or 32x32x16 (0) */
+    int32_t t128x256_m16;    /* 128x256 tile: 2-stage 16x16x32 form on stride-1 layers (1) or the 3-stage ring (0) */
+    int32_t small16;         /* 128x128 tiles on 16x16x32 everywhere (0) */
+    int32_t bigk;            /* K from which Cout >= 128 layers use the 8-wave tiles (256); creation time only */
+    int32_t tailsplit;       /* two-phase launches against wave quantisation (1) */
+    int32_t chsplit;         /* 256 + 128 channel split of the 384-channel head (1) */
+    int32_t k1tile;          /* single-stage streaming tiles for HBM-bound layers: 0 off, 1..3 (3) */
+    int32_t k1_maxk;         /* ... for 1x1 layers with K <= this (512) */
+    int32_t splitk_minsteps; /* K-steps from which few-tile launches split K (12) */
+    int32_t t64;             /* 64x64 tiles for latency-bound launches: 0 off, 1 never split K, 2 split K (2) */
+    int32_t t64_maxb;        /* ... when at most this many 128x128 tiles (256) */
+    int32_t t64_minsteps;    /* ... split K from this many K-steps (24) */
+    int32_t t64_s4;          /* ring of four for the 64x64 tile (0) */
+    int32_t s4;              /* ring of four for the latency-bound 128x128 tile (0) */
+    int32_t stemfuse;        /* fused stem + max pool (1); creation time only */
+    int32_t prefuse;         /* preprocessing inside the stem's patch loader (1); creation time only */
+    int32_t headmerge;       /* the shared head as one multi-level launch per conv (1); creation time only */
+    int32_t upfuse;          /* bilinear x2 upsamples computed inside the consuming conv (1); creation time only */
+    int32_t k1_generic;      /* the generic softmax/candidate kernel also for 81 classes (0) */
+    int32_t ablate;          /* timing only: bit 0 / bit 1 drop the activation / weight stream (results are garbage) */
+    int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
+    int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
+    int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
+    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan (0) */
+    int32_t reserved[7];     /* -1 */
+} yh_tuning;
+
 typedef struct yh_config {
     int32_t abi_version;   /* must be YH_ABI_VERSION */
     int32_t device;        /* HIP device ordinal */
@@ -64,8 +104,10 @@ typedef struct yh_config {
     float nms_thresh;      /* 0.5 */
     int32_t use_graph;     /* 1: capture the forward in a hipGraph after the first invoke */
     int32_t debug_tensors; /* 1: also materialise tensors that production runs fuse away (the pre-pool
-                            * "stem" tensor) for yh_debug_read_tensor; 0 (default): do not */
-    int32_t reserved[7];   /* zero */
+                            * "stem" tensor, the bilinear upsamples) for yh_debug_read_tensor; 0 (default): do not */
+    int32_t precision;     /* YH_PRECISION_F16 (default) | YH_PRECISION_FP8 */
+    int32_t reserved[6];   /* zero */
+    yh_tuning tune;        /* yh_default_config sets every field to -1 */
 } yh_config;
 
 /* Mirrors tflite TensorInfo {name, element_kind, dims, params{scale, zero_point}} as read at
@@ -92,8 +134,13 @@ typedef struct yh_detection {
 /* edgetpu::version() (src/scene.rs:62). Static string. */
 const char* yh_version(void);
 
-/* Fills *cfg with the YOLACT-550 R50 defaults. */
+/* Fills *cfg with the YOLACT-550 R50 defaults (every tuning field -1). */
 void yh_default_config(yh_config* cfg);
+/* Replaces the run-time tuning fields of a live handle (captured graphs are dropped and re-captured on the next
+ * call); YH_ESTATE if a creation-time field (bigk, stemfuse, prefuse, headmerge, upfuse) differs from the handle's. */
+int yh_set_tuning(yh_engine* h, const yh_tuning* tune);
+/* The handle's tuning with every default resolved (plan_cus = the CU count the plans really use, ...). */
+int yh_get_tuning(const yh_engine* h, yh_tuning* out);
 
 /* FlatBufferModel::build_from_file + InterpreterBuilder::new/build + EdgeTpuContext::open_device +
  * set_num_threads + allocate_tensors (src/yolact.rs:18-35): builds the layer table for cfg,
@@ -205,6 +252,8 @@ typedef struct yh_tfl yh_tfl;
 int yh_tfl_validate(const void* model_bytes, size_t nbytes, int32_t* n_tensors, int32_t* n_ops, char* err, size_t err_cap);
 /* FlatBufferModel::build_from_file + InterpreterBuilder + allocate_tensors (src/yolact.rs:18-35). */
 int yh_tfl_create(const void* model_bytes, size_t nbytes, int32_t device, yh_tfl** out);
+/* Same with the TFLite fields of a tuning struct (tfl_dot, tfl_graph; tune may be NULL). */
+int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, const yh_tuning* tune, yh_tfl** out);
 void yh_tfl_destroy(yh_tfl* h);
 const char* yh_tfl_last_error(const yh_tfl* h);
 int yh_tfl_input_info(const yh_tfl* h, yh_tensor_info* info);                 /* inputs()[0], :149-150 */
@@ -224,6 +273,8 @@ int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, in
  * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. "stem" is
  * fused into the pool kernel and only materialised by engines created with debug_tensors = 1 (YH_ESTATE otherwise). */
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst_host, size_t nfloats, int32_t dims[4]);
+/* Same for ONE frame of the batch (dims receives {1,h,w,c}): a batch-64 tensor is gigabytes as f32. */
+int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, float* dst_host, size_t nfloats, int32_t dims[4]);
 /* Test hook: number of conv kernel launches the last yh_op_conv2d_f16 on this handle was planned as
  * (1 = single launch, 2 = two-phase or channel-split plan; the split-K reduce is not counted). */
 int yh_debug_last_conv_launches(const yh_engine* h);

@@ -107,7 +107,7 @@ static int conv_table(const orc_net_cfg* cfg, convspec* s) {
     for (int i = 0; i < 4; ++i) ADD(256, 256, 3, 1.0f, 0);                              /* proto 0..3 */
     ADD(32, 256, 1, 1.0f, 0);                                                           /* proto out */
     ADD(256, 256, 3, 1.0f, 0);                                                          /* head trunk */
-    ADD(12, 256, 3, 0.1f, 0);                                                           /* box */
+    ADD(12, 256, 3, 2.0f, 0);                                                           /* box */
     ADD(3 * cfg->num_classes, 256, 3, 0.7f, 1);                                         /* conf */
     ADD(96, 256, 3, 0.5f, 0);                                                           /* mask */
 #undef ADD
@@ -139,7 +139,7 @@ static float unit_rand(uint64_t seed, uint64_t conv, uint64_t stream, uint64_t e
     return ((float)(uint32_t)(u >> 40) - 8388608.0f) * (1.0f / 8388608.0f);
 }
 
-#define CONF_BG_BIAS 7.5f
+#define CONF_BG_BIAS 10.0f
 
 int orc_weights_generate(const orc_net_cfg* cfg, uint64_t seed, void* blob, size_t nbytes) {
     if (nbytes != orc_weights_nbytes(cfg)) return -1;

@@ -30,8 +30,41 @@ def test_version_and_defaults(built):
     assert b"gfx950" in L.yh_version()
     cfg = capi.Config()
     L.yh_default_config(cfg)
-    assert (cfg.abi_version, cfg.backbone, cfg.input_size, cfg.num_classes, cfg.top_k, cfg.max_dets) == (1, 50, 550, 81, 200, 100)
+    assert (cfg.abi_version, cfg.backbone, cfg.input_size, cfg.num_classes, cfg.top_k, cfg.max_dets) == (2, 50, 550, 81, 200, 100)
     assert abs(cfg.conf_thresh - 0.05) < 1e-7 and cfg.nms_thresh == 0.5
+    assert cfg.precision == capi.PRECISION_F16 and all(v == -1 for v in cfg.tune.as_dict().values())
+
+
+def test_struct_layouts_match_the_header(built, tmp_path):
+    """The ctypes mirrors of yh_config / yh_tuning / yh_detection / yh_tensor_info have the C header's sizes and
+    field offsets (checked with a C program compiled against include/yolact_hip.h)."""
+    import ctypes as C
+    import subprocess
+    from yolact_amd import capi
+    src = tmp_path / "layout.c"
+    fields = ["tune.plan_cus", "tune.tfl_graph", "precision", "debug_tensors", "conf_thresh"]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yolact_hip.h"\nint main(void) {\n'
+                   'printf("%zu %zu %zu %zu", sizeof(yh_config), sizeof(yh_tuning), sizeof(yh_detection), sizeof(yh_tensor_info));\n'
+                   + "".join(f'printf(" %zu", offsetof(yh_config, {f}));\n' for f in fields) + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(capi.Config), C.sizeof(capi.Tuning), C.sizeof(capi.Detection), C.sizeof(capi.TensorInfo),
+            capi.Config.tune.offset + capi.Tuning.plan_cus.offset, capi.Config.tune.offset + capi.Tuning.tfl_graph.offset,
+            capi.Config.precision.offset, capi.Config.debug_tensors.offset, capi.Config.conf_thresh.offset]
+    assert got == want
+
+
+def test_library_reads_no_environment_variable(built):
+    """'No global state' (include/yolact_hip.h): every measurement switch is a field of yh_tuning on the handle; the
+    product sources never call getenv and the built library does not even import it."""
+    import subprocess
+    from yolact_amd import capi
+    csrc = os.path.join(ROOT, "tiny-object-detection_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f), errors="ignore").read(), f
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", capi.lib_path()], text=True)
+    assert "getenv" not in undefined
 
 
 def test_no_cpu_fallback(built):

@@ -28,43 +28,51 @@ def test_geometry_matches_published_yolact550(eng550):
     assert abs(eng.flops_per_frame() / 1e9 - 118.28) < 0.05
 
 
-def test_one_frame_550_vs_oracle(eng550, oracle, golden_dir):
-    """Restated acceptance target at full size: frc_balls.png resized to 550x550,
-    HIP engine vs CPU oracle in f16-storage mode. NOT parity with CPU tflite (model file absent)."""
-    from PIL import Image
-    eng, blob = eng550
-    img = np.asarray(Image.open(os.path.join(golden_dir, "frc_balls.png")).convert("RGB").resize((S, S), Image.BILINEAR))[None]
+def _vs_oracle(eng, net, oracle, img):
+    """Engine and oracle on one frame: returns (engine heads, engine dets, oracle heads, oracle dets)."""
     eng.set_input(img)
     eng.evaluate()
     got = [eng.output(i) for i in range(4)]
-    dets, masks = eng.detections(0)
-    net = oracle.Net(50, S, 81, blob=blob)
+    dets = eng.detections(0)
     want = net.forward(img, f16=True)
-    for name, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
-        assert np.abs(a - b).max() <= 0.03 * max(1.0, np.abs(b).max()), name
-        assert np.sqrt(((a - b) ** 2).mean()) <= 5e-3 * np.sqrt((b ** 2).mean()) + 1e-4, name
-    # tail bit-exact on the engine's own head outputs
-    odets, omasks = oracle.detect(got[0][0], got[1][0], got[2][0], got[3][0], net.priors())
-    assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
-    assert np.array_equal(masks, omasks)
-    # end to end against the oracle's own pipeline: matched detections, class ids equal, mask IoU >= 0.99
-    fdets, fmasks = oracle.detect(want[0][0], want[1][0], want[2][0], want[3][0], net.priors())
-    key = {(d["class_id"], d["prior"]): i for i, d in enumerate(dets)}
-    matched = [(key[(d["class_id"], d["prior"])], j) for j, d in enumerate(fdets) if (d["class_id"], d["prior"]) in key]
-    # Which of ~19 000 near-tied candidates survive Fast-NMS and the top-100 cut is a discrete decision:
-    # with seeded (untrained) weights many same-class neighbours sit at IoU ~ 0.5 with scores that
-    # differ in the 4th digit, so a few survivors flip on summation-order noise (8-11 of 100 here,
-    # whatever the tile choice). What must hold: most detections match, and for EVERY oracle detection
-    # the engine's own softmax probability for that (class, prior) agrees with the oracle's score.
-    assert len(fdets) > 0 and len(matched) >= 0.8 * len(fdets)
-    conf = got[1][0]
-    for d in fdets:
-        z = conf[d["prior"]].astype(np.float64)
-        pe = np.exp(z - z.max()); pe /= pe.sum()
-        assert abs(pe[d["class_id"] + 1] - d["score"]) <= 5e-3, d
-    inter = sum(int((masks[i] & fmasks[j]).sum()) for i, j in matched)
-    union = sum(int((masks[i] | fmasks[j]).sum()) for i, j in matched)
-    assert inter / max(union, 1) >= 0.99
+    odets = oracle.detect(want[0][0], want[1][0], want[2][0], want[3][0], net.priors())
+    return got, dets, want, odets
+
+
+def test_one_frame_550_vs_oracle(eng550, oracle, golden_dir):
+    """Restated acceptance target at full size: frc_balls.png resized to 550x550, HIP engine vs
+    CPU oracle in f16-storage mode: every detection matched by (class id, prior) and mask IoU >= 0.99 computed
+    over ALL detections of both sides (per-class union of masks: an unmatched detection counts against it).
+    NOT parity with CPU tflite (model file absent). A second, dense frame (uniform noise: 100 detections) has the
+    same bar with at most 3 of 100 detections allowed to differ: which of ~130 candidates sits on which side of
+    the 0.05 score threshold or the IoU-0.5 NMS test is a discrete decision, and with seeded (untrained) weights a
+    few candidates lie within the f16 summation-order noise of those thresholds."""
+    import bench
+    from PIL import Image
+    eng, blob = eng550
+    net = oracle.Net(50, S, 81, blob=blob)
+    balls = np.asarray(Image.open(os.path.join(golden_dir, "frc_balls.png")).convert("RGB").resize((S, S), Image.BILINEAR))[None]
+    noise = np.random.default_rng(5).integers(0, 256, (1, S, S, 3), dtype=np.uint8)
+    for name, img, min_dets, max_unmatched in (("frc_balls", balls, 5, 0), ("noise", noise, 90, 3)):
+        got, (dets, masks), want, (fdets, fmasks) = _vs_oracle(eng, net, oracle, img)
+        for tn, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
+            assert np.abs(a - b).max() <= 0.03 * max(1.0, np.abs(b).max()), (name, tn)
+            assert np.sqrt(((a - b) ** 2).mean()) <= 5e-3 * np.sqrt((b ** 2).mean()) + 1e-4, (name, tn)
+        # tail bit-exact on the engine's own head outputs
+        odets, omasks = oracle.detect(got[0][0], got[1][0], got[2][0], got[3][0], net.priors())
+        assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
+        assert np.array_equal(masks, omasks)
+        # end to end against the oracle's own pipeline, over ALL detections
+        acc = bench.accuracy_vs_oracle((dets, masks), (fdets, fmasks))
+        assert acc["oracle_dets"] >= min_dets, (name, acc)
+        assert acc["unmatched_oracle"] <= max_unmatched and acc["unmatched_engine"] <= max_unmatched, (name, acc)
+        assert acc["mask_iou_all"] >= 0.99, (name, acc)
+        # and for EVERY oracle detection the engine's own softmax probability for that (class, prior) agrees
+        conf = got[1][0]
+        for d in fdets:
+            z = conf[d["prior"]].astype(np.float64)
+            pe = np.exp(z - z.max()); pe /= pe.sum()
+            assert abs(pe[d["class_id"] + 1] - d["score"]) <= 5e-3, (name, d)
 
 
 def test_batch_properties_at_full_size(eng550):
@@ -132,4 +140,119 @@ def test_conv_linearity_exact_at_full_layer_size(built, oracle):
     # a sample of rows against the oracle (the whole layer would take the oracle a while)
     sub = oracle.conv2d(x[:, :10], w, b, 1, 1, None, 0, f16=True)
     assert np.abs(sub[:, :9] - y1[:, :9]).max() <= 2.0 ** -9 * max(1.0, np.abs(sub).max())
+    eng.close()
+
+
+# ---- configs[2]: batch 64, hipGraph steady state (BASELINE.json; tiles -> batch entries, src/yolact.rs:216-217) ----
+LAYERS_550 = (("pool", 2e-3), ("c2", 6e-3), ("c3", 1e-2), ("c4", 1.5e-2), ("c5", 2e-2), ("lat5", 2e-2), ("lat4", 2e-2), ("lat3", 2e-2),
+              ("p3", 2e-2), ("p4", 2e-2), ("p5", 2e-2), ("p6", 2.5e-2), ("p7", 2.5e-2), ("proto0", 2.5e-2), ("proto2", 2.5e-2), ("proto3", 3e-2),
+              ("head_t0", 3e-2), ("head_t2", 3e-2), ("head_t4", 3e-2))
+
+
+@pytest.fixture(scope="module")
+def eng64(built):
+    import yolact_amd as ya
+    e = ya.Engine(input_size=S, max_batch=64, use_graph=True)
+    blob = e.generate_weights(seed=1)
+    e.load_weights(blob)
+    frames = np.random.default_rng(64).integers(0, 256, (64, S, S, 3), dtype=np.uint8)
+    yield e, blob, frames
+    e.close()
+
+
+def test_batch64_launch_plans_are_the_ones_the_bench_runs(eng64):
+    """The headline configuration picks its tiles and launch plans from M = 64 * P * Q: the streaming 1x1 tiles,
+    the two-phase /rounds + /tail plan and the 256 + 128 channel split must really be launched at this size."""
+    eng, _, frames = eng64
+    eng.set_input(frames)
+    eng.evaluate()
+    names = [p["name"] for p in eng.profile(with_tail=True, reps=1)]
+    assert eng.tuning()["plan_cus"] == 256                                   # MI355X: the device's own CU count
+    assert sum("conv_igemm_f16<128,128,2,2,0,1>" in n for n in names) >= 20    # K1 streaming tiles (>= 1024 tiles each)
+    assert any(n.endswith("/rounds") for n in names) and any(n.endswith("/tail") for n in names)
+    assert any(n.endswith("/ch0-255") for n in names) and any(n.endswith("/ch256-383") for n in names)
+    assert any("conv_igemm_f16<256,256,2,4,0,2,mfma16>" in n and n.endswith(":proto3") for n in names)
+    assert not any("splitk" in n for n in names if ":p7" not in n)            # split-K is a small-batch plan
+
+
+def test_batch64_determinism_permutation_and_tail_bit_exact(eng64, oracle):
+    eng, blob, frames = eng64
+    eng.set_input(frames)
+    eng.evaluate()
+    heads_a = [eng.output(i) for i in range(4)]
+    dets_a = [eng.detections(f) for f in range(64)]
+    # determinism under graph replay
+    eng.set_input(frames)
+    eng.evaluate()
+    for i in range(4):
+        assert np.array_equal(eng.output(i), heads_a[i])
+    # frame-permutation equivariance over the 64 slots: a row's bits do not depend on the tile, round or launch
+    # phase (rounds / tail, channel split) that computed it
+    perm = np.random.default_rng(1).permutation(64)
+    eng.set_input(frames[perm])
+    eng.evaluate()
+    for i in range(4):
+        assert np.array_equal(eng.output(i), heads_a[i][perm])
+    for f in range(64):
+        d, m = eng.detections(f)
+        assert d == dets_a[perm[f]][0] and np.array_equal(m, dets_a[perm[f]][1])
+    # the detection tail of EVERY frame, bit for bit, against the oracle on the engine's own head outputs
+    pri = oracle.Net(50, S, 81, blob=blob).priors()
+    total = 0
+    for f in range(64):
+        dets, masks = dets_a[f]
+        odets, omasks = oracle.detect(heads_a[0][f], heads_a[1][f], heads_a[2][f], heads_a[3][f], pri)
+        assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets], f
+        assert np.array_equal(masks, omasks), f
+        total += len(dets)
+    assert total >= 64 * 50
+
+
+def test_batch64_one_slot_layer_by_layer_vs_oracle(eng64, oracle):
+    """One frame at a random slot of the batch-64 run against the oracle's forward: every named layer the production
+    path materialises (the layer-by-layer check that used to exist only at 128 x 128), the heads, and the detections."""
+    import bench
+    eng, blob, frames = eng64
+    slot = 37
+    eng.set_input(frames)
+    eng.evaluate()
+    net = oracle.Net(50, S, 81, blob=blob)
+    want = net.forward(frames[slot:slot + 1], f16=True)
+    for name, tol in LAYERS_550:
+        a, b = eng.tensor_frame(name, slot), net.get(name)[0]
+        assert a.shape == b.shape, name
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    got = [eng.output(i)[slot] for i in range(4)]
+    for tn, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
+        assert np.abs(a - b[0]).max() <= 0.03 * max(1.0, np.abs(b).max()), tn
+        assert np.sqrt(((a - b[0]) ** 2).mean()) <= 5e-3 * np.sqrt((b ** 2).mean()) + 1e-4, tn
+    fd = oracle.detect(want[0][0], want[1][0], want[2][0], want[3][0], net.priors())
+    acc = bench.accuracy_vs_oracle(eng.detections(slot), fd)
+    assert acc["oracle_dets"] >= 50 and acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and acc["mask_iou_all"] >= 0.99, acc
+
+
+# ---- configs[4] geometry in f16: YOLACT-700 ResNet-101, one frame ----
+def test_yolact700_r101_one_frame_vs_oracle(built, oracle):
+    import bench
+    import yolact_amd as ya
+    S7 = 700
+    eng = ya.Engine(input_size=S7, backbone=101, max_batch=1, use_graph=True)
+    blob = eng.generate_weights(seed=1)
+    eng.load_weights(blob)
+    assert eng.P == 30963 and (eng.hp, eng.wp) == (176, 176)                  # SURVEY.md Appendix B: levels 88/44/22/11/6
+    assert abs(eng.flops_per_frame() / 1e9 - 262.93) < 0.1
+    net = oracle.Net(101, S7, 81, blob=blob)
+    img = np.random.default_rng(7).integers(0, 256, (1, S7, S7, 3), dtype=np.uint8)
+    got, dets, want, fd = _vs_oracle(eng, net, oracle, img)
+    for name, tol in (("c2", 6e-3), ("c3", 1e-2), ("c4", 2.5e-2), ("c5", 3e-2), ("p3", 3e-2), ("p7", 3.5e-2), ("proto3", 4e-2), ("head_t0", 4e-2)):
+        a, b = eng.tensor_frame(name, 0), net.get(name)[0]
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    for tn, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
+        assert np.abs(a - b).max() <= 0.04 * max(1.0, np.abs(b).max()), tn
+        assert np.sqrt(((a - b) ** 2).mean()) <= 8e-3 * np.sqrt((b ** 2).mean()) + 1e-4, tn
+    odets, omasks = oracle.detect(got[0][0], got[1][0], got[2][0], got[3][0], net.priors())
+    assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets[0]] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
+    assert np.array_equal(dets[1], omasks)
+    acc = bench.accuracy_vs_oracle(dets, fd)
+    assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and (acc["mask_iou_all"] is None or acc["mask_iou_all"] >= 0.99), acc
     eng.close()

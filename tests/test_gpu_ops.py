@@ -95,9 +95,8 @@ def test_conv_exact_on_integers_big_tiles(eng, oracle, cin, cout, k):
 ])
 def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n, h, w):
     """Two-phase (wave-quantisation tail) and channel-split launch plans, reached with small
-    tensors by planning for a 4-CU chip (YH_PLAN_CUS): same bits as the oracle, and the same
+    tensors by planning for a 4-CU chip (tune.plan_cus = 4 on this handle): same bits as the oracle, and the same
     bits as the single-launch plan."""
-    import os
     rng = np.random.default_rng(cin + cout + k)
     x = f16(rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32))
     wt = f16(rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32))
@@ -105,12 +104,12 @@ def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n,
     r = f16(rng.integers(-5, 6, (n, h, w, cout)).astype(np.float32))
     single = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
     assert eng.last_conv_launches() == 1
-    os.environ["YH_PLAN_CUS"] = "4"
+    eng.set_tuning(plan_cus=4)
     try:
         split = eng.op_conv2d(x, wt, b, 1, k // 2, r, 1)
         assert eng.last_conv_launches() == 2          # the plan under test was really taken
     finally:
-        os.environ.pop("YH_PLAN_CUS")
+        eng.reset_tuning("plan_cus")
     yo = oracle.conv2d(x, wt, b, 1, k // 2, r, 1, f16=True)
     assert np.array_equal(split, yo) and np.array_equal(single, yo)
 
@@ -118,18 +117,17 @@ def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n,
 def test_conv_two_phase_plan_is_bitwise_identical_on_random_data(eng):
     """Random (non-exact) data: the tail phase's 128x128 16x16x32 tiles must accumulate each output
     element in the same order as the 256x256 tile, so the plan cannot change a single bit."""
-    import os
     rng = np.random.default_rng(77)
     x = f16(rng.normal(0, 1, (5, 17, 16, 128)))
     wt = f16(rng.normal(0, 1, (256, 3, 3, 128)) / 34)
     b = rng.normal(0, 0.1, 256).astype(np.float32)
     single = eng.op_conv2d(x, wt, b, 1, 1, None, 1)
-    os.environ["YH_PLAN_CUS"] = "4"
+    eng.set_tuning(plan_cus=4)
     try:
         split = eng.op_conv2d(x, wt, b, 1, 1, None, 1)
         assert eng.last_conv_launches() == 2
     finally:
-        os.environ.pop("YH_PLAN_CUS")
+        eng.reset_tuning("plan_cus")
     assert np.array_equal(single, split)
 
 
@@ -184,16 +182,12 @@ def test_stem_pool_fused_vs_oracle_random(eng, oracle):
 _TILES = {"128x128": 0, "128x256": 5, "128x128_S3": 7, "256x256_M16": 8, "128x128_M16": 12, "128x128_S3_M16": 13, "128x256_M16": 15, "64x64_S3": 16}
 
 
-def _forced(env, fn):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+def _forced(eng, tune, fn):
+    eng.set_tuning(**tune)
     try:
         return fn()
     finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k)
-            else: os.environ[k] = v
+        eng.reset_tuning(*tune)
 
 
 @pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _TILES] + [("128x128_S3", 3), ("64x64_S3", 4)])
@@ -209,9 +203,9 @@ def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
     x = rng.integers(-3, 4, (n, cells, cin)).astype(np.float32)
     wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
     b = rng.integers(-4, 5, cout).astype(np.float32)
-    env = {"YH_OP_TILE": _TILES[tile]}
-    if kslices: env["YH_OP_KSLICES"] = kslices
-    y = _forced(env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
+    env = {"op_tile": _TILES[tile]}
+    if kslices: env["op_kslices"] = kslices
+    y = _forced(eng, env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
     off = 0
     for s_ in sizes:
         xl = x[:, off:off + s_ * s_].reshape(n, s_, s_, cin)
@@ -229,9 +223,9 @@ def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     wt = rng.integers(-2, 3, (192, 3, 3, 128)).astype(np.float32)
     b = rng.integers(-4, 5, 192).astype(np.float32)
     r = rng.integers(-5, 6, (2, 13, 11, 192)).astype(np.float32)
-    env = {"YH_OP_TILE": _TILES[tile]}
-    if kslices: env["YH_OP_KSLICES"] = kslices
-    y = _forced(env, lambda: eng.op_conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1))
+    env = {"op_tile": _TILES[tile]}
+    if kslices: env["op_kslices"] = kslices
+    y = _forced(eng, env, lambda: eng.op_conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1))
     assert np.array_equal(y, oracle.conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1, f16=True))
 
 

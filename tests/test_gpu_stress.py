@@ -2,8 +2,6 @@
 exact, so any summation order gives the same bits): the conv kernel's tile variants and forced split-K, the
 multi-level form, the fused stem + pool - each against the oracle bit for bit. A longer run of the same
 generators (1 182 + 263 + 340 cases) was clean when they were written."""
-import os
-
 import numpy as np
 import pytest
 
@@ -20,19 +18,13 @@ def eng(built):
     e.close()
 
 
-def _with_env(env, fn):
-    keys = ("YH_OP_TILE", "YH_OP_KSLICES")
-    old = {k: os.environ.get(k) for k in keys}
-    for k in keys:
-        os.environ.pop(k, None)
-    os.environ.update({k: str(v) for k, v in env.items()})
+def _forced(eng, tune, fn):
+    """Runs fn with the single-op test knobs (op_tile, op_kslices) of THIS handle set, then clears them."""
+    eng.set_tuning(**tune)
     try:
         return fn()
     finally:
-        for k in keys:
-            os.environ.pop(k, None)
-            if old[k] is not None:
-                os.environ[k] = old[k]
+        eng.reset_tuning("op_tile", "op_kslices")
 
 
 def test_conv_random_shapes_and_tiles(eng, oracle):
@@ -49,15 +41,15 @@ def test_conv_random_shapes_and_tiles(eng, oracle):
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
         if ho < 1 or wo < 1:
             continue
-        env = {"YH_OP_TILE": tile}
+        env = {"op_tile": tile}
         ksl = int(rng.choice([0, 0, 2, 3])) if tile in (7, 16) else 0
         if ksl and k * k * cin // 64 >= ksl:
-            env["YH_OP_KSLICES"] = ksl
+            env["op_kslices"] = ksl
         x = rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)
         wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
         b = rng.integers(-4, 5, cout).astype(np.float32)
         r = rng.integers(-5, 6, (n, ho, wo, cout)).astype(np.float32) if res else None
-        y = _with_env(env, lambda: eng.op_conv2d(x, wt, b, stride, pad, r, act))
+        y = _forced(eng, env, lambda: eng.op_conv2d(x, wt, b, stride, pad, r, act))
         assert np.array_equal(y, oracle.conv2d(x, wt, b, stride, pad, r, act, f16=True)), (TILES[tile], n, h, w, cin, cout, k, stride, pad, res, act, env)
         done += 1
 
@@ -68,15 +60,15 @@ def test_multilevel_random_levels_and_tiles(eng, oracle):
         sizes = [int(rng.integers(1, 14)) for _ in range(int(rng.integers(1, 6)))]
         n, cin, cout, k = int(rng.integers(1, 4)), int(rng.choice([64, 128])), int(rng.choice([64, 128, 256, 351])), int(rng.choice([1, 3]))
         tile = int(rng.choice([0, 5, 7, 8, 12, 13, 15, 16]))
-        env = {"YH_OP_TILE": tile}
+        env = {"op_tile": tile}
         ksl = int(rng.choice([0, 2, 3])) if tile in (7, 16) else 0
         if ksl and k * k * cin // 64 >= ksl:
-            env["YH_OP_KSLICES"] = ksl
+            env["op_kslices"] = ksl
         cells = sum(s * s for s in sizes)
         x = rng.integers(-3, 4, (n, cells, cin)).astype(np.float32)
         wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
         b = rng.integers(-4, 5, cout).astype(np.float32)
-        y = _with_env(env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
+        y = _forced(eng, env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
         off = 0
         for s_ in sizes:
             yo = oracle.conv2d(x[:, off:off + s_ * s_].reshape(n, s_, s_, cin), wt, b, 1, k // 2, None, 1, f16=True)

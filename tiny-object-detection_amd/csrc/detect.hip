@@ -18,7 +18,6 @@
 //                         registers, coefficients of all detections sit in LDS; mask bit =
 //                         (fma chain > 0) && inside crop window   [sigmoid(x) > 0.5 <=> x > 0].
 #include "yh_internal.h"
-#include <cstdlib>
 
 namespace yh {
 
@@ -402,8 +401,7 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
         case 0: return hipMemsetAsync(p.cls_count, 0, sizeof(int) * (size_t)p.n * (p.C - 1), s);
         case 1: {
             const dim3 grid((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n);
-            static const bool generic = getenv("YH_K1_GENERIC") && atoi(getenv("YH_K1_GENERIC"));   // A/B switch (tools/)
-            if (p.C == 81 && !generic) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
+            if (p.C == 81 && !p.k1_generic) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
             else hipLaunchKernelGGL(det_softmax_cand, grid, dim3(192), (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -60,9 +61,6 @@ struct Op {
     int P = 0, Q = 0;      // output spatial
     int nlev = 0, lev_start[5] = {0, 0, 0, 0, 0}, lev_h[5] = {0, 0, 0, 0, 0}, lev_w[5] = {0, 0, 0, 0, 0};   // multi-level input (ConvParams)
     double flops_per_img = 0, bytes_per_img = 0, bytes_fixed = 0;
-    int lane = 0;              // stream the op runs on when branch concurrency is on
-    std::vector<int> deps;     // producer ops on OTHER lanes (RAW through in / res)
-    bool signal = false;       // some op on another lane consumes this op's output
 };
 
 size_t pad16(size_t v) { return (v + 15u) & ~(size_t)15u; }
@@ -88,15 +86,30 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 
 }  // namespace
 
-static const int yh_engine_lanes = 4;
+// The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
+struct Tune {
+    int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices;
+};
+static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
+    auto d = [](int v, int def) { return v < 0 ? def : v; };
+    Tune r;
+    r.plan_cus = t.plan_cus > 0 ? t.plan_cus : device_cus;
+    r.mfma16 = d(t.mfma16, 1); r.t128x256_m16 = d(t.t128x256_m16, 1); r.small16 = d(t.small16, 0); r.bigk = d(t.bigk, 256);
+    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 3); r.k1_maxk = d(t.k1_maxk, 512);
+    r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
+    r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
+    r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
+    return r;
+}
+
 struct yh_engine {
     yh_config cfg;
-    int dev = 0;
+    Tune tune;
+    int dev = 0, device_cus = 256;
     hipStream_t stream = nullptr;
-    static const int kLanes = 4;
-    hipStream_t lanes[kLanes] = { nullptr, nullptr, nullptr, nullptr };  // lanes[0] == stream
-    std::vector<hipEvent_t> op_done;   // one per op that signals another lane
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
+    hipStream_t side = nullptr;   // the detection tail's K1-K3 run here underneath the protonet
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     int S = 0, C = 0, ldh = 0;
@@ -110,6 +123,7 @@ struct yh_engine {
     std::vector<Op> ops;
     std::vector<void*> allocs;
     std::map<std::string, Buf> named;
+    std::set<std::string> fused_away;   // named tensors that production runs never write (debug_tensors = 1 materialises them)
 
     uint8_t* in_u8 = nullptr;
     int in_hp = 0;
@@ -130,7 +144,7 @@ struct yh_engine {
     // output staging
     float* out_f32 = nullptr;
     size_t out_f32_cap = 0;
-    float* splitk_ws[yh_engine_lanes] = { nullptr, nullptr, nullptr, nullptr };  // one per lane (lanes run concurrently)
+    float* splitk_ws = nullptr;
     static const size_t kSplitKBytes = (size_t)48 << 20;
 
     bool weights_loaded = false;
@@ -210,7 +224,7 @@ void build_conv_table(yh_engine* h) {
     for (int i = 0; i < 4; ++i) add(256, 256, 3, 1.0f, 0);
     add(32, 256, 1, 1.0f, 0);
     add(256, 256, 3, 1.0f, 0);
-    add(12, 256, 3, 0.1f, 0);
+    add(12, 256, 3, 2.0f, 0);
     add(3 * h->C, 256, 3, 0.7f, 1);
     add(96, 256, 3, 0.5f, 0);
     size_t off = 16;
@@ -239,8 +253,7 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     else p.tile = TILE_128x128;
     p.Kpad = d0.cin == 3 ? round_up(d0.k * ((d0.k + 1) / 2), 8) * 8 : d0.k * d0.k * d0.cin;  // stem: k rows x ceil(k/2) chunks
     // K-heavy layers (>= 8 steps of 64): 8-wave tiles on the 3-stage LDS-DMA ring
-    static const int bigk = getenv("YH_BIGK") ? atoi(getenv("YH_BIGK")) : 256;   // A/B switch (tools/)
-    if (p.tile == TILE_128x128 && p.Kpad >= bigk) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    if (p.tile == TILE_128x128 && p.Kpad >= h->tune.bigk) p.tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
     p.coutPad = round_up(cout, conv_tile_ch(p.tile));
     h->panels.push_back(p);
     return (int)h->panels.size() - 1;
@@ -278,12 +291,10 @@ int build_graph_spec(yh_engine* h) {
     if ((rc = new_buf(h, "input", h->in_hp, h->in_hp, 4, &h->in_f16))) return rc;
 
     int ci = 0;  // canonical conv cursor
-    // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or YH_STEMFUSE=0; its patch
-    // loader then also does the preprocessing (raw RGB -> normalised f16) unless YH_PREFUSE=0.
-    static const int stemfuse = getenv("YH_STEMFUSE") ? atoi(getenv("YH_STEMFUSE")) : 1;
-    static const int prefuse = getenv("YH_PREFUSE") ? atoi(getenv("YH_PREFUSE")) : 1;
-    h->stem_fused = stemfuse && (S % 2 == 0);
-    h->pre_fused = h->stem_fused && prefuse;
+    // Fused stem + pool (conv_igemm.hip: stem_pool_f16) unless the size is odd or tune.stemfuse = 0; its patch
+    // loader then also does the preprocessing (raw RGB -> normalised f16) unless tune.prefuse = 0.
+    h->stem_fused = h->tune.stemfuse && (S % 2 == 0);
+    h->pre_fused = h->stem_fused && h->tune.prefuse;
     if (!h->pre_fused) {
         Op o; o.kind = OP_PRE; o.name = "input"; o.label = "preprocess_rgb8_f16:input";
         o.bytes_per_img = (double)S * S * (3 + 8);
@@ -295,6 +306,7 @@ int build_graph_spec(yh_engine* h) {
     if ((rc = new_buf(h, "pool", H2, H2, 64, &pool))) return rc;
     // (the "stem" tensor is only materialised for engines created with debug_tensors = 1: test hook)
     if (h->stem_fused) {
+        h->fused_away.insert("stem");
         Op o;
         o.kind = OP_STEMPOOL; o.name = "pool"; o.label = "stem_pool_f16:stem+pool";
         o.panel = add_panel(h, { ci++ });
@@ -399,9 +411,9 @@ int build_graph_spec(yh_engine* h) {
     const int ci_end = ci;
     // The head's weights are shared by the five levels, whose cells lie end to end in the pyramid
     // buffers: ONE launch per head conv covers all of them (multi-level input: every tap stays inside its
-    // row's own level), instead of five launches of which three have a handful of tiles. YH_HEADMERGE=0
+    // row's own level), instead of five launches of which three have a handful of tiles. tune.headmerge = 0
     // restores one launch per level.
-    static const int headmerge = getenv("YH_HEADMERGE") ? atoi(getenv("YH_HEADMERGE")) : 1;
+    const int headmerge = h->tune.headmerge;
     auto merged = [&](const char* name, int panel, const Buf& in, const Buf& out, int act) {
         Buf bi = in, bo = out;
         bi.h = bo.h = h->cells; bi.w = bo.w = 1;
@@ -451,27 +463,6 @@ int build_graph_spec(yh_engine* h) {
     h->ops.push_back(conv_op(h, "proto", add_panel(h, { ci++ }), p3b, h->proto, 1, 0, 1, nullptr));
     ci = ci_end;
     if (ci != (int)h->convs.size()) return h->fail(YH_EINVAL, "conv table / graph mismatch");
-    // ---- branch concurrency: lanes by role, cross-lane RAW dependencies found by buffer pointer
-    // (every tensor is written exactly once per step and never aliased, so RAW is the only hazard)
-    for (Op& o : h->ops) {
-        const std::string& n = o.name;
-        auto ends = [&](const char* suf) { const size_t l = strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
-        if (ends("_d") || n == "p5" || n == "p6" || n == "p7" || n == "head_t2" || n == "head_out2" || n == "head_t3" ||
-            n == "head_out3" || n == "head_t4" || n == "head_out4") o.lane = 1;
-        else if (n == "p4" || n == "head_t1" || n == "head_out1") o.lane = 2;
-        else if (n == "head_t0" || n == "head_out0" || n == "head_t" || n == "head_out") o.lane = 3;
-        else o.lane = 0;
-    }
-    for (size_t i = 0; i < h->ops.size(); ++i) {
-        Op& o = h->ops[i];
-        const half_t* srcs[2] = { o.kind == OP_PRE ? nullptr : o.in.d, o.has_res ? o.res.d : nullptr };
-        for (const half_t* sp : srcs) {
-            if (!sp) continue;
-            for (size_t j = 0; j < i; ++j)
-                if (h->ops[j].kind != OP_PRE ? h->ops[j].out.d == sp : h->in_f16.d == sp)
-                    if (h->ops[j].lane != o.lane) { o.deps.push_back((int)j); h->ops[j].signal = true; }
-        }
-    }
     h->flops_per_frame = 0;
     for (const Op& o : h->ops) h->flops_per_frame += o.flops_per_img;
     return YH_OK;
@@ -521,6 +512,7 @@ int alloc_tail(yh_engine* h) {
     d.P = h->P; d.cells = h->cells; d.ldh = h->ldh; d.C = h->C; d.hp = h->hp; d.wp = h->wp;
     d.top_k = h->cfg.top_k; d.max_dets = h->cfg.max_dets;
     d.conf_thresh = h->cfg.conf_thresh; d.nms_thresh = h->cfg.nms_thresh;
+    d.k1_generic = h->tune.k1_generic;
     return YH_OK;
 }
 
@@ -529,79 +521,67 @@ int alloc_tail(yh_engine* h) {
 // ------------------------------------------------------------------------------------------------
 // The panel fixes the widest channel tile (coutPad); per launch, fall back to the 4-wave
 // 128 x 128 tile (2 workgroups per CU) when the big tile would leave most of the 256 CUs idle.
-ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml);
+ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int pad, bool ml);
 // ml: the op has a multi-level input (only the tiles launch_conv instantiates for it may be chosen)
-ConvTile pick_tile(const Panel& pn, int M, int stride = 0, int pad = 0, bool ml = false) {
-    // A/B switch (tools/): the 16x16x32 forms of the 128 x 128 tiles everywhere
-    static const int small16 = getenv("YH_SMALL16") ? atoi(getenv("YH_SMALL16")) : 0;
-    const ConvTile t = pick_tile_base(pn, M, stride, pad, ml);
-    static const int s4 = getenv("YH_S4") ? atoi(getenv("YH_S4")) : 0;   // A/B switch (tools/): ring of four for the latency-bound tile
-    if (s4 && !ml && t == TILE_128x128_S3) return TILE_128x128_S4;
+ConvTile pick_tile(const Tune& tu, const Panel& pn, int M, int stride = 0, int pad = 0, bool ml = false) {
+    const ConvTile t = pick_tile_base(tu, pn, M, stride, pad, ml);
+    if (tu.s4 && !ml && t == TILE_128x128_S3) return TILE_128x128_S4;   // A/B: ring of four for the latency-bound tile
     // Latency-bound launches with few 128 x 128 tiles: 64 x 64 tiles put four times as many workgroups on
-    // the idle CUs and a K step costs a wave 4 MFMAs instead of 16 (A/B switch YH_T64; 0 = off)
-    static const int t64 = getenv("YH_T64") ? atoi(getenv("YH_T64")) : 2;
-    static const int t64_max = getenv("YH_T64_MAXB") ? atoi(getenv("YH_T64_MAXB")) : 256;
-    static const int t64_s4 = getenv("YH_T64_S4") ? atoi(getenv("YH_T64_S4")) : 0;
-    if (t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= t64_max) return t64_s4 && !ml ? TILE_64x64_S4 : TILE_64x64_S3;
+    // the idle CUs and a K step costs a wave 4 MFMAs instead of 16 (tune.t64; 0 = off)
+    if (tu.t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= tu.t64_maxb) return tu.t64_s4 && !ml ? TILE_64x64_S4 : TILE_64x64_S3;
     // 128 x 256: the 2-stage 16x16x32 form measures ~5 % faster than the 3-stage 32x32x16 ring on stride-1
     // layers (0.112 vs 0.118 ms on the 69 x 69 3x3 convs at batch 64) and slower on the stride-2 one
-    static const int t128m16 = getenv("YH_128X256_M16") ? atoi(getenv("YH_128X256_M16")) : 1;   // A/B switch (tools/)
-    if (t128m16 && t == TILE_128x256 && stride == 1) return TILE_128x256_M16;
-    if (small16 && t == TILE_128x128) return TILE_128x128_M16;
-    if (small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
+    if (tu.t128x256_m16 && t == TILE_128x256 && stride == 1) return TILE_128x256_M16;
+    if (tu.small16 && t == TILE_128x128) return TILE_128x128_M16;
+    if (tu.small16 >= 2 && t == TILE_128x128_S3 && pn.Kpad / 64 < 8) return TILE_128x128_S3_M16;   // (split-K keeps the 32x32x16 form)
     return t;
 }
-ConvTile pick_tile_base(const Panel& pn, int M, int stride, int pad, bool ml) {
+ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int pad, bool ml) {
     if (pn.tile == TILE_256x256 || pn.tile == TILE_128x256) {
         const int tm = conv_tile_m(pn.tile), tch = conv_tile_ch(pn.tile);
         const long long blocks = (long long)((M + tm - 1) / tm) * (pn.coutPad / tch);
-        if (blocks < 192) {
+        if (blocks < tu.plan_cus * 3 / 4) {
             // latency-bound launches (at most one workgroup per CU): the 3-stage ring hides the
             // L2 round trip of every 64-deep K step
             const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
-            return b128 <= 256 ? TILE_128x128_S3 : TILE_128x128;
+            return b128 <= tu.plan_cus ? TILE_128x128_S3 : TILE_128x128;
         }
     }
     // HBM-bound 1x1 layers (K <= 512): the single-stage "streaming" forms keep 34-40 KB of LDS per workgroup,
     // so four workgroups share a CU instead of two and their load and store phases overlap each other
-    // (4.0 -> 5.2 TB/s on the 69 x 69 expand convs at batch 64). A/B switch: YH_K1TILE=0.
-    static const int k1 = getenv("YH_K1TILE") ? atoi(getenv("YH_K1TILE")) : 3;   // 1: 128x128 form only, 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3
-    static const int k1_maxk = getenv("YH_K1_MAXK") ? atoi(getenv("YH_K1_MAXK")) : 512;
-    if (k1 && !ml && pn.k == 1 && pn.Kpad <= k1_maxk) {
-        if (pn.coutPad % 128 == 0 && pn.cout > 64 && (long long)((M + 127) / 128) * (pn.coutPad / 128) >= 1024) return TILE_128x128_K1;
-        if (k1 >= 2 && pn.tile == TILE_64x256 && (M + 255) / 256 >= 1024) return TILE_64x256_K1;
+    // (4.0 -> 5.2 TB/s on the 69 x 69 expand convs at batch 64). tune.k1tile: 0 off, 1: 128x128 form only,
+    // 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3.
+    const int k1 = tu.k1tile;
+    const long long k1_min = 4ll * tu.plan_cus;   // (1024 tiles on the 256-CU part)
+    if (k1 && !ml && pn.k == 1 && pn.Kpad <= tu.k1_maxk) {
+        if (pn.coutPad % 128 == 0 && pn.cout > 64 && (long long)((M + 127) / 128) * (pn.coutPad / 128) >= k1_min) return TILE_128x128_K1;
+        if (k1 >= 2 && pn.tile == TILE_64x256 && (M + 255) / 256 >= k1_min) return TILE_64x256_K1;
     }
     // (the 64-channel 3x3 convs of layer 1 too: 590 -> 715 TFLOP/s - their LDS fill per MFMA is what binds them, and
     // four co-resident workgroups overlap it better than a double buffer inside two)
-    if (k1 >= 3 && !ml && pn.k == 3 && pn.tile == TILE_64x256 && (M + 255) / 256 >= 1024) return TILE_64x256_K1;
+    if (k1 >= 3 && !ml && pn.k == 3 && pn.tile == TILE_64x256 && (M + 255) / 256 >= k1_min) return TILE_64x256_K1;
     if (pn.tile == TILE_128x128 && pn.Kpad >= 256) {
         const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
-        if (b128 <= 256) return TILE_128x128_S3;
+        if (b128 <= tu.plan_cus) return TILE_128x128_S3;
     }
-    static const int mfma16 = getenv("YH_MFMA16") ? atoi(getenv("YH_MFMA16")) : 1;   // A/B switch (tools/): default 16x16x32
-    if (pn.tile == TILE_256x256 && (mfma16 || ml)) return TILE_256x256_M16;
+    if (pn.tile == TILE_256x256 && (tu.mfma16 || ml)) return TILE_256x256_M16;
     return pn.tile;
 }
 
-// Launch planning. The CU count the plan assumes can be overridden (YH_PLAN_CUS) so that the tests
-// reach both split forms with small tensors; the results do not depend on the plan.
-static int plan_cus() {
-    const char* e = getenv("YH_PLAN_CUS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 256;
-}
+// Launch planning. The CU count the plans assume is the device's (hipDeviceProp_t.multiProcessorCount) unless
+// tune.plan_cus overrides it, so that the tests reach both split forms with small tensors; the results do not
+// depend on the plan.
 
 // Wave quantisation: the 8-wave tiles run one workgroup per CU, so a grid of r * 256 + t workgroups
 // takes r + 1 rounds however small t is (35 x 35 levels at batch 64: 307 workgroups = 2 rounds for
 // 1.2 rounds of work). When the last round would be less than half full, the launch is split:
 // the first r * 256 workgroups' rows on the big tile, the remaining rows on 128 x 128 tiles (two
 // workgroups per CU, a quarter of the work each), which fill the chip again. Returns the number of
-// big row tiles in phase one, 0 = single launch. A/B switch: YH_TAILSPLIT=0.
-int tail_split_tiles(int coutPad, const ConvParams& p, ConvTile tile) {
-    static const int on = getenv("YH_TAILSPLIT") ? atoi(getenv("YH_TAILSPLIT")) : 1;
-    if (!on || p.k_slices > 1 || coutPad % 128 != 0 || p.m_tile0 || p.ch_tile0) return 0;
+// big row tiles in phase one, 0 = single launch. tune.tailsplit = 0 turns it off.
+int tail_split_tiles(const Tune& tu, int coutPad, const ConvParams& p, ConvTile tile) {
+    if (!tu.tailsplit || p.k_slices > 1 || coutPad % 128 != 0 || p.m_tile0 || p.ch_tile0) return 0;
     if (tile != TILE_256x256_M16) return 0;   // the only big tile whose bits the small 16x16x32 tiles reproduce
-    const int cus = plan_cus();
+    const int cus = tu.plan_cus;
     const int tm = conv_tile_m(tile), nch = coutPad / conv_tile_ch(tile);
     const int m_tiles = (p.M + tm - 1) / tm;
     const long long blocks = (long long)m_tiles * nch;
@@ -615,16 +595,16 @@ int tail_split_tiles(int coutPad, const ConvParams& p, ConvTile tile) {
 // algorithmic work a launch does (profile attribution), `what` a label suffix.
 struct KLaunch { bool reduce; ConvParams p; ConvTile tile; double frac; const char* what; };
 
-int plan_conv(const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
+int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
     if (p.k_slices > 1) {   // split-K: main kernel + slab reduction
         out[0] = KLaunch{ false, p, tile, 1.0, "/splitk" };
         out[1] = KLaunch{ true, p, tile, 0.0, "" };
         return 2;
     }
     // channel split: 384 padded output channels (the shared head's 351) = one 256-wide tile on the
-    // fastest kernel + one 128-wide tile, instead of three 128-wide ones. A/B switch: YH_CHSPLIT=0.
-    static const int chsplit = getenv("YH_CHSPLIT") ? atoi(getenv("YH_CHSPLIT")) : 1;
-    const int mt256 = (p.M + 255) / 256, cus = plan_cus();
+    // fastest kernel + one 128-wide tile, instead of three 128-wide ones (tune.chsplit = 0: off).
+    const int chsplit = tu.chsplit;
+    const int mt256 = (p.M + 255) / 256, cus = tu.plan_cus;
     // (only where the 256-wide launch's last round is reasonably full: it runs one workgroup per CU)
     const bool rounds_ok = mt256 >= 4 * cus || mt256 % cus == 0 || mt256 % cus > cus / 2;
     if (chsplit && (tile == TILE_128x256 || tile == TILE_128x256_M16) && coutPad == 384 && mt256 >= cus * 3 / 4 && rounds_ok) {
@@ -636,7 +616,7 @@ int plan_conv(const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
         out[1] = KLaunch{ false, b, TILE_128x128, 128.0 / 384.0, "/ch256-383" };
         return 2;
     }
-    const int mt1 = tail_split_tiles(coutPad, p, tile);
+    const int mt1 = tail_split_tiles(tu, coutPad, p, tile);
     if (mt1 == 0) { out[0] = KLaunch{ false, p, tile, 1.0, "" }; return 1; }
     // two-phase launch: whole rounds of the big tile, then the remaining rows on 128 x 128 tiles whose
     // 16x16x32 MFMA form accumulates every output element in the same order as the big tile does,
@@ -647,7 +627,7 @@ int plan_conv(const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
     b.n_ch_tiles = coutPad / 128;
     const long long tb = (long long)((p.M - a.M + 127) / 128) * b.n_ch_tiles;
     out[0] = KLaunch{ false, a, tile, (double)a.M / p.M, "/rounds" };
-    out[1] = KLaunch{ false, b, tb <= plan_cus() ? TILE_128x128_S3_M16 : TILE_128x128_M16, (double)(p.M - a.M) / p.M, "/tail" };
+    out[1] = KLaunch{ false, b, tb <= tu.plan_cus ? TILE_128x128_S3_M16 : TILE_128x128_M16, (double)(p.M - a.M) / p.M, "/tail" };
     return 2;
 }
 
@@ -655,9 +635,9 @@ hipError_t launch_k(const KLaunch& k, hipStream_t stream) {
     return k.reduce ? launch_splitk_reduce(k.p, stream) : launch_conv(k.p, k.tile, stream);
 }
 
-hipError_t launch_conv_planned(const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
+hipError_t launch_conv_planned(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
     KLaunch k[2];
-    const int nk = plan_conv(p, tile, coutPad, k);
+    const int nk = plan_conv(tu, p, tile, coutPad, k);
     if (n_launches) *n_launches = p.k_slices > 1 ? 1 : nk;   // (the split-K reduce is not counted: include/yolact_hip.h)
     for (int i = 0; i < nk; ++i) {
         const hipError_t e = launch_k(k[i], stream);
@@ -690,24 +670,20 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     p.act = o.act; p.tanh_from = o.tanh_from;
     p.nlev = o.nlev;
     for (int l = 0; l < 5; ++l) { p.lev_start[l] = o.lev_start[l]; p.lev_h[l] = o.lev_h[l]; p.lev_w[l] = o.lev_w[l]; }
-    // timing-only ablation (tools/): zero-record descriptors drop every load through them
-    static const int ablate = getenv("YH_ABLATE") ? atoi(getenv("YH_ABLATE")) : 0;
-
-    if (ablate & 1) { p.x_bytes = 0; }
-    if (ablate & 2) { p.w_bytes = 0; }
-    const ConvTile tile = pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0);
+    // timing-only ablation (tune.ablate): zero-record descriptors drop every load through them
+    if (h->tune.ablate & 1) { p.x_bytes = 0; }
+    if (h->tune.ablate & 2) { p.w_bytes = 0; }
+    const ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
-    static const int splitk_min = getenv("YH_SPLITK_MINSTEPS") ? atoi(getenv("YH_SPLITK_MINSTEPS")) : 12;   // A/B switch (tools/)
-    static const int t64_mode = getenv("YH_T64") ? atoi(getenv("YH_T64")) : 2;
-    static const int t64_min = getenv("YH_T64_MINSTEPS") ? atoi(getenv("YH_T64_MINSTEPS")) : 24;
+    const int splitk_min = h->tune.splitk_minsteps, t64_mode = h->tune.t64, t64_min = h->tune.t64_minsteps;
     const bool ring128 = tile == TILE_128x128_S3 || tile == TILE_128x128_S4;
     const bool ring64 = (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && t64_mode >= 2;
     if ((ring128 && p.ksteps >= splitk_min) || (ring64 && p.ksteps >= t64_min)) {
         // few tiles, long K: split K so that about one workgroup per CU streams the weights
         const int tm = conv_tile_m(tile);
         const long long tiles = (long long)((p.M + tm - 1) / tm) * p.n_ch_tiles;
-        int sl = (int)((ring64 ? 512 : 256) / tiles);
+        int sl = (int)((ring64 ? 2 * h->tune.plan_cus : h->tune.plan_cus) / tiles);
         if (sl > p.ksteps / 4) sl = p.ksteps / 4;  // at least 4 steps per slice
         if (sl > 16) sl = 16;
         const size_t need = (size_t)sl * p.M * pn.coutPad * 4;
@@ -716,7 +692,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
             p.ksteps_per_slice = (p.ksteps + sl - 1) / sl;
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = pn.coutPad;
-            p.partial = h->splitk_ws[o.lane];
+            p.partial = h->splitk_ws;
         }
     }
     if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
@@ -735,7 +711,7 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             int rc = fill_conv_params(h, o, n, &p);
             if (rc) return rc;
             const Panel& pn = h->panels[o.panel];
-            e = launch_conv_planned(p, pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, h->stream);
+            e = launch_conv_planned(h->tune, p, pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, h->stream);
             break;
         }
         case OP_POOL:
@@ -761,73 +737,29 @@ int launch_op(yh_engine* h, const Op& o, int n) {
     return YH_OK;
 }
 
-int launch_op_on(yh_engine* h, const Op& o, int n, hipStream_t st) {
-    hipStream_t keep = h->stream;
-    h->stream = st;
-    const int rc = launch_op(h, o, n);
-    h->stream = keep;
-    return rc;
-}
-
 int enqueue_all(yh_engine* h, int n, int with_tail) {
-    // Default: one stream, except that the tail's K1-K3 fork onto lane 1 underneath the protonet.
-    // Optional (YH_LANES_MAXN=n): for batches <= n every independent branch (projection convs, FPN
-    // levels, the shared head per level, the protonet) gets its own lane, joined by events (valid
-    // under stream capture). That paid at batch 1 before split-K existed (1.8 -> 1.5 ms); with
-    // split-K filling the GPU per launch it measures 0-6 % slower at every batch size, so it is off.
-    static const int lanes_maxn = getenv("YH_LANES_MAXN") ? atoi(getenv("YH_LANES_MAXN")) : 0;   // A/B switch (tools/)
-    const bool multi = n <= lanes_maxn;
+    // One stream, except that the tail's K1-K3 (softmax/append, per-class NMS, frame top-k: small latency-bound
+    // grids that need only the head rows) fork onto the side stream underneath the protonet's convolutions and
+    // join before the mask kernel (event record / wait: valid under stream capture).
     bool tail_forked = false;
-    if (!multi) {
-        for (size_t i = 0; i < h->ops.size(); ++i) {
-            if (with_tail && (int)i == h->tail_fork_op) {
-                // heads are complete: softmax/append, per-class NMS and frame top-k (small, latency-
-                // bound grids) run on lane 1 underneath the protonet's convolutions
-                h->det.n = n;
-                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-                HIPCHK(h, hipStreamWaitEvent(h->lanes[1], h->ev_fork, 0));
-                for (int st = 0; st < 4; ++st)
-                    if (launch_detect_stage(h->det, st, h->lanes[1]) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
-                HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + 1], h->lanes[1]));
-                tail_forked = true;
-            }
-            int rc = launch_op(h, h->ops[i], n);
-            if (rc) return rc;
-        }
-    } else {
-        bool used[yh_engine::kLanes] = { true, false, false, false };
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // fork point
-        for (size_t i = 0; i < h->ops.size(); ++i) {
-            const Op& o = h->ops[i];
-            hipStream_t st = h->lanes[o.lane];
-            if (!used[o.lane]) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_fork, 0)); used[o.lane] = true; }
-            for (int j : o.deps) HIPCHK(h, hipStreamWaitEvent(st, h->op_done[j], 0));
-            int rc = launch_op_on(h, o, n, st);
-            if (rc) return rc;
-            if (o.signal) HIPCHK(h, hipEventRecord(h->op_done[i], st));
-        }
-        // every lane's work so far is marked by one event per lane
-        for (int l = 1; l < yh_engine::kLanes; ++l)
-            if (used[l]) HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + l], h->lanes[l]));
-        if (with_tail && used[1]) {
-            // K1-K3 need only the head rows (lanes 1-3): run them on lane 1 while lane 0 still works
-            // through the protonet; the mask kernel joins both
-            for (int l = 2; l < yh_engine::kLanes; ++l)
-                if (used[l]) HIPCHK(h, hipStreamWaitEvent(h->lanes[1], h->op_done[h->ops.size() + l], 0));
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        if (with_tail && (int)i == h->tail_fork_op) {
             h->det.n = n;
+            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
             for (int st = 0; st < 4; ++st)
-                if (launch_detect_stage(h->det, st, h->lanes[1]) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
-            HIPCHK(h, hipEventRecord(h->op_done[h->ops.size() + 1], h->lanes[1]));
+                if (launch_detect_stage(h->det, st, h->side) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
+            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
             tail_forked = true;
         }
-        for (int l = 1; l < yh_engine::kLanes; ++l)
-            if (used[l]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + l], 0));   // join
+        int rc = launch_op(h, h->ops[i], n);
+        if (rc) return rc;
     }
     if (with_tail) {
         h->det.n = n;
         hipError_t e;
         if (tail_forked) {
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->op_done[h->ops.size() + 1], 0));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             e = launch_detect_stage(h->det, 4, h->stream);   // masks: need the prototypes too
         } else e = launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
@@ -962,6 +894,8 @@ void yh_default_config(yh_config* cfg) {
     cfg->conf_thresh = 0.05f;
     cfg->nms_thresh = 0.5f;
     cfg->use_graph = 1;
+    cfg->precision = YH_PRECISION_F16;
+    memset(&cfg->tune, 0xFF, sizeof cfg->tune);   // every tuning field -1: the library's defaults
 }
 
 const char* yh_last_error(const yh_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -973,7 +907,8 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     if ((cfg->backbone != YH_BACKBONE_R50 && cfg->backbone != YH_BACKBONE_R101) || cfg->input_size < 64 ||
         cfg->input_size > 1024 || cfg->max_batch < 1 || cfg->max_batch > 256 || cfg->num_classes < 5 ||
         cfg->num_classes > 81 || cfg->top_k < 1 || cfg->top_k > 256 || cfg->max_dets < 1 || cfg->max_dets > 128 ||
-        (cfg->num_classes - 1) * cfg->top_k > 16384 || (cfg->debug_tensors != 0 && cfg->debug_tensors != 1)) {
+        (cfg->num_classes - 1) * cfg->top_k > 16384 || (cfg->debug_tensors != 0 && cfg->debug_tensors != 1) ||
+        (cfg->precision != YH_PRECISION_F16 && cfg->precision != YH_PRECISION_FP8)) {
         g_create_error = "configuration out of range";
         return YH_EINVAL;
     }
@@ -987,6 +922,11 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     h->dev = cfg->device;
     h->S = cfg->input_size;
     h->C = cfg->num_classes;
+    {   // launch plans are made for the CU count of THIS device (tune.plan_cus overrides it for the tests)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->device_cus = prop.multiProcessorCount;
+        h->tune = resolve_tuning(cfg->tune, h->device_cus);
+    }
     auto bail = [&](int rc) {
         g_create_error = h->err;
         yh_destroy(h);
@@ -994,25 +934,22 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     };
     hipError_t e = hipSetDevice(h->dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    h->lanes[0] = h->stream;
-    for (int l = 1; l < yh_engine::kLanes && e == hipSuccess; ++l) e = hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev0, hipEventDefault);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("device setup: ") + hipGetErrorString(e); return bail(YH_EHIP); }
     build_conv_table(h);
     int rc = build_graph_spec(h);
     if (rc) return bail(rc);
-    h->op_done.assign(h->ops.size() + yh_engine::kLanes, nullptr);
-    for (auto& ev : h->op_done)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { h->err = "hipEventCreate"; return bail(YH_EHIP); }
     build_priors(h);
     if ((rc = alloc_tail(h))) return bail(rc);
     if ((rc = alloc_panels(h))) return bail(rc);
-    for (int l = 0; l < yh_engine_lanes; ++l) {
+    {
         void* q = nullptr;
         if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
-        h->splitk_ws[l] = (float*)q;
+        h->splitk_ws = (float*)q;
     }
     e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
@@ -1033,14 +970,42 @@ void yh_destroy(yh_engine* h) {
     if (h->codes_dev) hipFree(h->codes_dev);
     if (h->stitch_dev) hipFree(h->stitch_dev);
     if (h->diverged_dev) hipFree(h->diverged_dev);
-    for (hipEvent_t ev : h->op_done) if (ev) hipEventDestroy(ev);
-    for (int l = 1; l < yh_engine::kLanes; ++l) if (h->lanes[l]) { hipStreamSynchronize(h->lanes[l]); hipStreamDestroy(h->lanes[l]); }
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     for (int k = 0; k < 2; ++k) { if (h->stage_ev[k]) hipEventDestroy(h->stage_ev[k]); if (h->stage[k]) hipHostFree(h->stage[k]); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
+}
+
+int yh_set_tuning(yh_engine* h, const yh_tuning* tune) {
+    if (!h || !tune) return YH_EINVAL;
+    const Tune t = resolve_tuning(*tune, h->device_cus);
+    if (t.bigk != h->tune.bigk || t.stemfuse != h->tune.stemfuse || t.prefuse != h->tune.prefuse || t.headmerge != h->tune.headmerge ||
+        t.upfuse != h->tune.upfuse)
+        return h->fail(YH_ESTATE, "bigk, stemfuse, prefuse, headmerge and upfuse are fixed when the handle is created");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // captured plans were made under the old tuning
+    h->graphs.clear();
+    h->tune = t;
+    h->cfg.tune = *tune;
+    h->det.k1_generic = t.k1_generic;
+    return YH_OK;
+}
+
+int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
+    if (!h || !out) return YH_EINVAL;
+    memset(out, 0xFF, sizeof *out);
+    const Tune& t = h->tune;
+    out->plan_cus = t.plan_cus; out->mfma16 = t.mfma16; out->t128x256_m16 = t.t128x256_m16; out->small16 = t.small16; out->bigk = t.bigk;
+    out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
+    out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
+    out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices;
+    return YH_OK;
 }
 
 size_t yh_weights_nbytes(const yh_engine* h) { return h ? h->blob_bytes : 0; }
@@ -1066,7 +1031,7 @@ int yh_weights_generate(const yh_engine* hc, uint64_t seed, void* blob_host, siz
         float* bias = (float*)(b + d.blob_b_off);
         for (int e = 0; e < d.cout; ++e) {
             float v = unit_rand(seed, i, 1, (uint64_t)e) * 0.1f;
-            if (d.is_conf && (e % h->C) == 0) v = v + 7.5f;
+            if (d.is_conf && (e % h->C) == 0) v = v + 10.0f;
             bias[e] = v;
         }
     }
@@ -1122,6 +1087,16 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
         return YH_OK;
     }
     HIPCHK(h, hipMemcpyAsync(h->in_u8, src, bytes, kind, h->stream));
+    if (kind == hipMemcpyHostToDevice) {
+        // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. The runtime
+        // stages an async copy from PAGEABLE memory before returning; from pinned / registered memory it is a true
+        // DMA that is still reading the buffer, so wait for it.
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
+            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(h, hipEventSynchronize(h->ev_fork));
+        } else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
+    }
     h->cur_n = n;
     return YH_OK;
 }
@@ -1349,8 +1324,8 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
-    if (h->stem_fused && !h->cfg.debug_tensors && strcmp(name, "stem") == 0)
-        return h->fail(YH_ESTATE, "the stem tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
+    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     const Buf& b = it->second;
     const int n = h->cur_n;
     const size_t per = (size_t)b.h * b.w * b.c;
@@ -1365,6 +1340,28 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
         if (e != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
     }
     HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+
+int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, float* dst, size_t nfloats, int32_t dims[4]) {
+    if (!h || !name || !dims) return YH_EINVAL;
+    auto it = h->named.find(name);
+    if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
+    if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
+    if (frame < 0 || frame >= h->cur_n) return h->fail(YH_EINVAL, "frame out of range");
+    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
+    const Buf& b = it->second;
+    const size_t per = (size_t)b.h * b.w * b.c;
+    dims[0] = 1; dims[1] = b.h; dims[2] = b.w; dims[3] = b.c;
+    if (!dst) return YH_OK;
+    if (nfloats < per) return h->fail(YH_EINVAL, "destination too small");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = ensure_out_f32(h, per);
+    if (rc) return rc;
+    if (launch_f16_to_f32(b.d + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->stream) != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
+    HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return YH_OK;
 }
@@ -1385,7 +1382,7 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         if (rc) return rc;
         const Panel& pn = h->panels[o.panel];
         KLaunch k[2];
-        const int nk = plan_conv(p, pick_tile(pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, k);
+        const int nk = plan_conv(h->tune, p, pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, k);
         for (int j = 0; j < nk; ++j) { ProfEntry e{}; e.op = i; e.stage = -1; e.k = k[j]; e.is_conv = true; out->push_back(e); }
     }
     if (with_tail)
@@ -1480,9 +1477,10 @@ static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh
     ConvTile tile = cin == 3 ? TILE_64x256_SMALLC : (cout <= 32 ? TILE_32x256 : (cout <= 64 ? TILE_64x256 : TILE_128x128));
     const int Kpad = cin == 3 ? round_up(k * k, 8) * 8 : k * k * cin;
     if (tile == TILE_128x128 && Kpad >= 512) tile = (cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
-    if (tile == TILE_256x256 && !(getenv("YH_MFMA16") && !atoi(getenv("YH_MFMA16")))) tile = TILE_256x256_M16;
-    if (tile == TILE_128x256 && stride == 1 && !(getenv("YH_128X256_M16") && !atoi(getenv("YH_128X256_M16")))) tile = TILE_128x256_M16;
-    if (getenv("YH_OP_TILE") && cin != 3) tile = (ConvTile)atoi(getenv("YH_OP_TILE"));   // test hook: force a tile variant
+    if (tile == TILE_256x256 && h->tune.mfma16) tile = TILE_256x256_M16;
+    if (tile == TILE_128x256 && stride == 1 && h->tune.t128x256_m16) tile = TILE_128x256_M16;
+    if (h->tune.op_tile >= 0 && cin != 3) tile = (ConvTile)h->tune.op_tile;   // test hook: force a tile variant
+    if (conv_tile_ch(tile) == 0) return h->fail(YH_EINVAL, "conv op: tune.op_tile is not a tile id");
     const int coutPad = round_up(cout, conv_tile_ch(tile)), cout8 = round_up(cout, 8);
     // host-side staging: pad input channels, repack weights, pad output rows to cout8
     std::vector<uint16_t> xs((size_t)n * hh * ww * cs, 0), wp((size_t)coutPad * Kpad, 0);
@@ -1527,14 +1525,14 @@ static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh
             for (int l = 0, st = 0; l < nlev; ++l) { p.lev_start[l] = st; p.lev_h[l] = p.lev_w[l] = level_sizes[l]; st += level_sizes[l] * level_sizes[l]; }
         }
         // test hook: a forced split-K (the engine decides it in fill_conv_params)
-        const int ksl = getenv("YH_OP_KSLICES") ? atoi(getenv("YH_OP_KSLICES")) : 0;
+        const int ksl = h->tune.op_kslices;
         if (ksl > 1 && ksl <= p.ksteps && (size_t)ksl * M * coutPad * 4 <= yh_engine::kSplitKBytes) {
             p.ksteps_per_slice = (p.ksteps + ksl - 1) / ksl;
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = coutPad;
-            p.partial = h->splitk_ws[0];
+            p.partial = h->splitk_ws;
         }
-        e = launch_conv_planned(p, tile, coutPad, h->stream, &h->last_conv_launches);
+        e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(ys.data(), dy, ys.size() * 2, hipMemcpyDeviceToHost);

@@ -20,7 +20,6 @@
 #include <vector>
 
 #include "tflite_model.h"
-#include <cstdlib>
 #include "yh_internal.h"
 
 using namespace yh;
@@ -291,6 +290,7 @@ struct yh_tfl {
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
     hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
+    int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
     // classify scratch
     uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
     uint8_t* tiles_dev = nullptr;
@@ -352,8 +352,7 @@ int prepare(yh_tfl* h) {
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
                 c.wsum = nullptr;
-                static const int use_dot = getenv("YH_TFL_DOT") ? atoi(getenv("YH_TFL_DOT")) : 1;   // A/B switch (tools/)
-                if (!dw && use_dot && c.Ci % 4 == 0 && w.data && (long long)c.kh * c.kw * c.Ci * 65025ll < (1ll << 31)) {
+                if (!dw && h->use_dot && c.Ci % 4 == 0 && w.data && (long long)c.kh * c.kw * c.Ci * 65025ll < (1ll << 31)) {
                     // per (channel, tap) sums of the raw weight bytes for the dot-product kernel
                     const int ntaps = c.kh * c.kw;
                     std::vector<int> ws((size_t)c.Co * ntaps, 0);
@@ -540,8 +539,7 @@ int enqueue_plan(yh_tfl* h) {
 // default because rocprofv3 --kernel-trace crashed inside hipGraphLaunch after ~110 replays of this
 // 137-kernel graph (the YOLACT engine's graphs replay under the profiler without trouble).
 int run_plan(yh_tfl* h) {
-    static const int use_graph = getenv("YH_TFL_GRAPH") ? atoi(getenv("YH_TFL_GRAPH")) : 0;
-    if (!use_graph) return enqueue_plan(h);
+    if (!h->use_graph) return enqueue_plan(h);
     if (!h->gexec) {
         hipGraph_t g = nullptr;
         TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
@@ -582,12 +580,18 @@ int yh_tfl_validate(const void* model_bytes, size_t nbytes, int32_t* n_tensors, 
 const char* yh_tfl_last_error(const yh_tfl* h) { return h ? h->err.c_str() : g_tfl_create_error.c_str(); }
 
 int yh_tfl_create(const void* model_bytes, size_t nbytes, int32_t device, yh_tfl** out) {
+    return yh_tfl_create_tuned(model_bytes, nbytes, device, nullptr, out);
+}
+
+int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, const yh_tuning* tune, yh_tfl** out) {
     if (!model_bytes || !out) { g_tfl_create_error = "null argument"; return YH_EINVAL; }
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_tfl_create_error = "no such HIP device (no CPU fallback)"; return YH_EHIP; }
     yh_tfl* h = new yh_tfl();
     h->dev = device;
+    if (tune && tune->tfl_dot >= 0) h->use_dot = tune->tfl_dot;
+    if (tune && tune->tfl_graph >= 0) h->use_graph = tune->tfl_graph;
     h->file.assign((const uint8_t*)model_bytes, (const uint8_t*)model_bytes + nbytes);
     auto bail = [&](int rc) { g_tfl_create_error = h->err; yh_tfl_destroy(h); return rc; };
     if (!h->m.parse(h->file.data(), h->file.size())) { h->err = "tflite parse: " + h->m.error; return bail(YH_EWEIGHTS); }

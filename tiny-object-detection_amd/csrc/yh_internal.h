@@ -102,6 +102,7 @@ struct DetectParams {
     const float* priors;  // [P][4]
     int n, P, cells, ldh, C, hp, wp, top_k, max_dets;
     float conf_thresh, nms_thresh;
+    int k1_generic;       // 1: the generic softmax/candidate kernel also for 81 classes (yh_tuning.k1_generic)
     // workspaces
     int* cls_count;       // [n][C-1]
     uint2* cand;          // [n][C-1][P]  {score bits, prior}

@@ -17,11 +17,36 @@ class YhError(RuntimeError):
         self.code = code
 
 
+PRECISION_F16, PRECISION_FP8 = 0, 1
+
+# yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
+TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
+                 "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph")
+
+
+class Tuning(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 7)]
+
+    @classmethod
+    def of(cls, **kw):
+        t = cls()
+        C.memset(C.byref(t), 0xFF, C.sizeof(t))
+        for k, v in kw.items():
+            assert k in TUNING_FIELDS, k
+            setattr(t, k, int(v))
+        return t
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f in TUNING_FIELDS}
+
+
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("backbone", C.c_int32),
                 ("input_size", C.c_int32), ("max_batch", C.c_int32), ("num_classes", C.c_int32),
                 ("top_k", C.c_int32), ("max_dets", C.c_int32), ("conf_thresh", C.c_float),
-                ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("debug_tensors", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("debug_tensors", C.c_int32),
+                ("precision", C.c_int32), ("reserved", C.c_int32 * 6), ("tune", Tuning)]
 
 
 class TensorInfo(C.Structure):
@@ -44,6 +69,8 @@ SYMBOLS = [
     ("yh_default_config", None, [C.POINTER(Config)]),
     ("yh_create", _i, [C.POINTER(Config), C.POINTER(_vp)]),
     ("yh_destroy", None, [_vp]),
+    ("yh_set_tuning", _i, [_vp, C.POINTER(Tuning)]),
+    ("yh_get_tuning", _i, [_vp, C.POINTER(Tuning)]),
     ("yh_last_error", C.c_char_p, [_vp]),
     ("yh_weights_nbytes", _sz, [_vp]),
     ("yh_weights_generate", _i, [_vp, C.c_uint64, _vp, _sz]),
@@ -72,6 +99,7 @@ SYMBOLS = [
     ("yh_flops_per_frame", C.c_double, [_vp]),
     ("yh_tfl_validate", _i, [_vp, _sz, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
     ("yh_tfl_create", _i, [_vp, _sz, _i, C.POINTER(_vp)]),
+    ("yh_tfl_create_tuned", _i, [_vp, _sz, _i, C.POINTER(Tuning), C.POINTER(_vp)]),
     ("yh_tfl_destroy", None, [_vp]),
     ("yh_tfl_last_error", C.c_char_p, [_vp]),
     ("yh_tfl_input_info", _i, [_vp, C.POINTER(TensorInfo)]),
@@ -84,6 +112,7 @@ SYMBOLS = [
     ("yh_tfl_tensor_read", _i, [_vp, _i, _vp, _sz]),
     ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
+    ("yh_debug_read_tensor_frame", _i, [_vp, C.c_char_p, _i, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -134,7 +163,8 @@ class Engine:
     """RAII wrapper of one yh_engine handle."""
 
     def __init__(self, input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100,
-                 conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0, debug_tensors=False):
+                 conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0, debug_tensors=False, precision=PRECISION_F16,
+                 tune=None):
         self.L = load_library()
         cfg = Config()
         self.L.yh_default_config(C.byref(cfg))
@@ -142,6 +172,10 @@ class Engine:
         cfg.num_classes, cfg.top_k, cfg.max_dets = num_classes, top_k, max_dets
         cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = conf_thresh, nms_thresh, 1 if use_graph else 0
         cfg.debug_tensors = 1 if debug_tensors else 0
+        cfg.precision = precision
+        if tune:
+            cfg.tune = Tuning.of(**tune)
+        self._tune = dict(tune or {})
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.L.yh_create(C.byref(cfg), C.byref(h))
@@ -166,6 +200,24 @@ class Engine:
     def _chk(self, rc):
         if rc != OK:
             raise YhError(rc, self.L.yh_last_error(self.h).decode())
+
+    # ---- tuning (per handle; the library reads no environment variable)
+    def set_tuning(self, **kw):
+        """Replaces the run-time tuning fields; fields not named keep what this wrapper last set."""
+        self._tune.update(kw)
+        t = Tuning.of(**self._tune)
+        self._chk(self.L.yh_set_tuning(self.h, C.byref(t)))
+
+    def reset_tuning(self, *names):
+        for k in names:
+            self._tune.pop(k, None)
+        t = Tuning.of(**self._tune)
+        self._chk(self.L.yh_set_tuning(self.h, C.byref(t)))
+
+    def tuning(self):
+        t = Tuning()
+        self._chk(self.L.yh_get_tuning(self.h, C.byref(t)))
+        return t.as_dict()
 
     # ---- weights
     def weights_nbytes(self):
@@ -267,6 +319,14 @@ class Engine:
         self._chk(self.L.yh_debug_read_tensor(self.h, name.encode(), None, 0, C.byref(d)))
         out = np.empty(tuple(d), np.float32)
         self._chk(self.L.yh_debug_read_tensor(self.h, name.encode(), _p(out), out.size, C.byref(d)))
+        return out
+
+    def tensor_frame(self, name, frame):
+        """One frame of a named intermediate as f32 [h][w][c] (test hook)."""
+        d = (C.c_int32 * 4)()
+        self._chk(self.L.yh_debug_read_tensor_frame(self.h, name.encode(), frame, None, 0, C.byref(d)))
+        out = np.empty(tuple(d)[1:], np.float32)
+        self._chk(self.L.yh_debug_read_tensor_frame(self.h, name.encode(), frame, _p(out), out.size, C.byref(d)))
         return out
 
     # ---- measurement hooks
@@ -397,10 +457,11 @@ _KIND_NP = {1: np.float32, 3: np.uint8, 2: np.int32}
 class TfliteEngine:
     """RAII wrapper of yh_tfl: the reference's own model family (uint8 MobileNetV2-style .tflite)."""
 
-    def __init__(self, model_bytes, device=0):
+    def __init__(self, model_bytes, device=0, tune=None):
         self.L = load_library()
         h = C.c_void_p()
-        rc = self.L.yh_tfl_create(model_bytes, len(model_bytes), device, C.byref(h))
+        t = Tuning.of(**(tune or {}))
+        rc = self.L.yh_tfl_create_tuned(model_bytes, len(model_bytes), device, C.byref(t), C.byref(h))
         if rc != OK:
             raise YhError(rc, self.L.yh_tfl_last_error(None).decode())
         self.h = h
