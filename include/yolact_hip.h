@@ -153,6 +153,9 @@ const char* yh_last_error(const yh_engine* h); /* h may be NULL: last create err
 
 /* Size in bytes of the canonical weight blob (DESIGN.md §Weight blob) for this architecture. */
 size_t yh_weights_nbytes(const yh_engine* h);
+/* The canonical blob as loaded, in device memory on the handle's device (NULL before a load): what
+ * yh_load_weights_device of another handle on the same device, or the RCCL broadcast below, reads. */
+const void* yh_weights_device_ptr(const yh_engine* h);
 /* Writes the seeded synthetic blob (He-scaled uniform, BN folded to bias) into host memory. The
  * reference's model file is absent (.MISSING_LARGE_BLOBS:1-2); this is its stand-in. */
 int yh_weights_generate(const yh_engine* h, uint64_t seed, void* blob_host, size_t nbytes);
@@ -162,6 +165,20 @@ int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes);
 /* Same, blob already in device memory on this handle's device (e.g. the receive buffer of an RCCL
  * broadcast from rank 0 over xGMI: SURVEY.md §8e). */
 int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
+
+/* ---- multi-GPU: the path's one collective (north_star: "weights replicated once via RCCL
+ * broadcast over xGMI, no per-step collectives"). The reference's caller is a Rust process (src/main.rs:63-75,
+ * src/scene.rs:63), not torch, so the broadcast is reachable through this ABI; librccl.so is opened on first use.
+ * Frames then shard over the handles with no further communication. ------------------------------------------- */
+#define YH_RCCL_ID_BYTES 128
+/* One process, one handle per GPU (a host thread + stream per device): copies the weights
+ * loaded on handles[root] to every other handle (ncclCommInitAll + grouped ncclBroadcast of the canonical blob,
+ * then the usual validation and repack on each device). */
+int yh_group_broadcast_weights(yh_engine** handles, int32_t n, int32_t root);
+/* One process per GPU: rank `root` has its weights loaded; every rank calls this with the same id (from
+ * yh_rccl_unique_id on one rank, handed to the others by the host's own means: ncclCommInitRank + ncclBroadcast). */
+int yh_rccl_unique_id(void* id_out /* YH_RCCL_ID_BYTES */);
+int yh_rank_broadcast_weights(yh_engine* h, const void* id, int32_t rank, int32_t nranks, int32_t root);
 
 /* ---- interpreter-shaped surface (lets classify_tile, src/yolact.rs:133-190, port unchanged) -- */
 

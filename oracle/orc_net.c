@@ -78,7 +78,7 @@ struct orc_net {
 };
 
 /* ------------------------------------------------------------------ canonical conv table */
-typedef struct { int cout, cin, k; float gain; int kind; } convspec; /* kind: 0 plain, 1 conf */
+typedef struct { int cout, cin, k; float gain; int kind; } convspec; /* kind: 0 plain, 1 conf, 2 mask */
 
 static int blocks_of(int backbone, int layer) {
     static const int r50[4] = { 3, 4, 6, 3 }, r101[4] = { 3, 4, 23, 3 };
@@ -109,7 +109,7 @@ static int conv_table(const orc_net_cfg* cfg, convspec* s) {
     ADD(256, 256, 3, 1.0f, 0);                                                          /* head trunk */
     ADD(12, 256, 3, 2.0f, 0);                                                           /* box */
     ADD(3 * cfg->num_classes, 256, 3, 0.7f, 1);                                         /* conf */
-    ADD(96, 256, 3, 0.5f, 0);                                                           /* mask */
+    ADD(96, 256, 3, 0.5f, 2);                                                           /* mask */
 #undef ADD
     return n;
 }
@@ -140,7 +140,11 @@ static float unit_rand(uint64_t seed, uint64_t conv, uint64_t stream, uint64_t e
 }
 
 #define CONF_BG_BIAS 10.0f
+#define MASK_BIAS 0.1f   /* mask logits are not centred on their decision threshold (weight blob) */
 
+/* fp-contract off: `u * 0.1f` and the bias constants added to it must stay two IEEE operations (this file is
+ * otherwise built with -ffp-contract=fast), or the blob differs from the engine's generator in the last bit. */
+__attribute__((optimize("fp-contract=off")))
 int orc_weights_generate(const orc_net_cfg* cfg, uint64_t seed, void* blob, size_t nbytes) {
     if (nbytes != orc_weights_nbytes(cfg)) return -1;
     int n = conv_table(cfg, NULL);
@@ -166,6 +170,7 @@ int orc_weights_generate(const orc_net_cfg* cfg, uint64_t seed, void* blob, size
         for (int e = 0; e < s[i].cout; ++e) {
             float v = unit_rand(seed, (uint64_t)i, 1, (uint64_t)e) * 0.1f;
             if (s[i].kind == 1 && (e % cfg->num_classes) == 0) v = v + CONF_BG_BIAS;
+            if (s[i].kind == 2) v = v + MASK_BIAS;
             b[e] = v;
         }
         p += pad16((size_t)s[i].cout * 4);

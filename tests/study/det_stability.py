@@ -33,6 +33,12 @@ def union_iou(d1, m1, d2, m2):
         inter += (u1 & u2).sum(); union += (u1 | u2).sum()
     return inter / max(union, 1)
 print("per-class union-of-masks IoU", union_iou(da, ma, db, mb))
+kb2 = {(d["class_id"], d["prior"]): j for j, d in enumerate(db)}
+i_ = u_ = 0
+for i, d in enumerate(da):
+    j = kb2.get((d["class_id"], d["prior"]))
+    if j is not None: i_ += (ma[i] & mb[j]).sum(); u_ += (ma[i] | mb[j]).sum()
+print("matched IoU", i_ / max(u_, 1), "mask fill", float(ma.mean()) if len(da) else 0)
 # candidates above threshold
 conf = a[1][0]; z = conf - conf.max(1, keepdims=True); p = np.exp(z); p /= p.sum(1, keepdims=True)
 print("candidates", int((p[:, 1:] > 0.05).sum()), "classes with dets", len(set(d["class_id"] for d in da)))

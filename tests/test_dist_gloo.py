@@ -34,6 +34,9 @@ def _worker(rank, world, port, nbytes, out_dir):
         bench.broadcast_weights(dist, blob)
         start, count = bench.shard_frames(129, world, rank)
         t = bench.max_over_ranks(dist, 1.0 + rank, "cpu")
+        # the branch every rank takes for the weight replication is agreed by one MIN all-reduce
+        agree = [bench.all_ranks_ok(dist, True, "cpu"), bench.all_ranks_ok(dist, rank != 1, "cpu"), bench.all_ranks_ok(dist, False, "cpu")]
+        np.save(os.path.join(out_dir, f"a{rank}.npy"), np.array(agree))
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([int(blob.sum()), start, count, t], np.float64))
         np.save(os.path.join(out_dir, f"b{rank}.npy"), blob.numpy())
         dist.barrier()
@@ -49,6 +52,8 @@ def test_two_rank_broadcast_shard_and_timing(tmp_path):
     assert np.array_equal(b[0], b[1]) and b[0].any()            # rank 1 received rank 0's blob
     assert (r[0][1], r[0][2]) == (0, 65) and (r[1][1], r[1][2]) == (65, 64)   # contiguous blocks of 129 frames
     assert r[0][3] == r[1][3] == 2.0                            # MAX over ranks
+    for k in range(world):                                      # one rank's failure sends BOTH ranks to the fallback
+        assert list(np.load(tmp_path / f"a{k}.npy")) == [True, False, False]
 
 
 def test_shard_frames_partitions_exactly():
@@ -73,7 +78,7 @@ def test_roofline_helper_picks_dominant_kernel():
 
 def test_accuracy_helper_matches_by_class_and_prior():
     """bench.accuracy_vs_oracle (the engine-vs-oracle report in the bench line): detections are matched
-    by (class, prior); the IoU is pooled over matched pairs only."""
+    by (class, prior); mask_iou_matched is pooled over matched pairs only, mask_iou_all over every detection."""
     import bench
     m = np.zeros((2, 4, 4), np.uint8); m[0, :2] = 1; m[1, 1:3, 1:3] = 1
     eng = ([dict(class_id=3, prior=7), dict(class_id=5, prior=9)], m)
@@ -82,7 +87,14 @@ def test_accuracy_helper_matches_by_class_and_prior():
     r = bench.accuracy_vs_oracle(eng, orc)
     assert r["oracle_dets"] == 3 and r["engine_dets"] == 2 and r["matched_class_and_prior"] == 2
     assert abs(r["mask_iou_matched"] - (8 + 4) / (9 + 4)) < 1e-4
-    assert bench.accuracy_vs_oracle(([], m[:0]), ([], m[:0]))["mask_iou_matched"] is None
+    # the figure that counts: per-class unions over ALL detections - the oracle-only detection (class 1, 16 pixels)
+    # adds its whole mask to the union and nothing to the intersection
+    assert r["unmatched_oracle"] == 1 and r["unmatched_engine"] == 0
+    assert abs(r["mask_iou_all"] - (8 + 4 + 0) / (9 + 4 + 16)) < 1e-4
+    same = bench.accuracy_vs_oracle(eng, eng)
+    assert same["mask_iou_all"] == 1.0 and same["unmatched_oracle"] == 0
+    e = bench.accuracy_vs_oracle(([], m[:0]), ([], m[:0]))
+    assert e["mask_iou_matched"] is None and e["mask_iou_all"] is None
 
 
 def test_measured_traffic_reads_the_committed_pmc_file():

@@ -6,6 +6,7 @@
 // intermediate inspectable), a private stream, the repacked weight panels, and the op list that
 // yh_invoke / yh_evaluate replay (optionally as a captured hipGraph).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
@@ -28,7 +29,7 @@ thread_local std::string g_create_error;
 struct ConvDesc {          // one canonical conv of the blob
     int cout, cin, k;
     float gain;
-    int is_conf;
+    int is_conf;   // 0 plain, 1 conf head (background bias), 2 mask head (bias)
     size_t blob_w_off, blob_b_off;  // byte offsets in the canonical blob
 };
 
@@ -148,6 +149,7 @@ struct yh_engine {
     static const size_t kSplitKBytes = (size_t)48 << 20;
 
     bool weights_loaded = false;
+    uint8_t* blob_dev = nullptr;   // the canonical blob as loaded (send / receive buffer of the RCCL weight broadcast)
     int cur_n = 0;
     static constexpr size_t kStageBytes = 4u << 20;   // pinned staging for small host inputs
     uint8_t* stage[2] = { nullptr, nullptr };
@@ -226,7 +228,7 @@ void build_conv_table(yh_engine* h) {
     add(256, 256, 3, 1.0f, 0);
     add(12, 256, 3, 2.0f, 0);
     add(3 * h->C, 256, 3, 0.7f, 1);
-    add(96, 256, 3, 0.5f, 0);
+    add(96, 256, 3, 0.5f, 2);
     size_t off = 16;
     for (auto& d : h->convs) {
         off += 16;
@@ -1009,6 +1011,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
 }
 
 size_t yh_weights_nbytes(const yh_engine* h) { return h ? h->blob_bytes : 0; }
+const void* yh_weights_device_ptr(const yh_engine* h) { return h && h->weights_loaded ? h->blob_dev : nullptr; }
 
 int yh_weights_generate(const yh_engine* hc, uint64_t seed, void* blob_host, size_t nbytes) {
     yh_engine* h = const_cast<yh_engine*>(hc);
@@ -1031,10 +1034,22 @@ int yh_weights_generate(const yh_engine* hc, uint64_t seed, void* blob_host, siz
         float* bias = (float*)(b + d.blob_b_off);
         for (int e = 0; e < d.cout; ++e) {
             float v = unit_rand(seed, i, 1, (uint64_t)e) * 0.1f;
-            if (d.is_conf && (e % h->C) == 0) v = v + 10.0f;
+            if (d.is_conf == 1 && (e % h->C) == 0) v = v + 10.0f;   // background logit: detections stay sparse
+            if (d.is_conf == 2) v = v + 0.1f;                         // mask head: logits not centred on their threshold
             bias[e] = v;
         }
     }
+    return YH_OK;
+}
+
+static int keep_blob(yh_engine* h, const void* src, hipMemcpyKind kind) {
+    if (!h->blob_dev) {
+        void* q = nullptr;
+        const int rc = dev_alloc(h, &q, h->blob_bytes);
+        if (rc) return rc;
+        h->blob_dev = (uint8_t*)q;
+    }
+    if (src != h->blob_dev) HIPCHK(h, hipMemcpy(h->blob_dev, src, h->blob_bytes, kind));
     return YH_OK;
 }
 
@@ -1042,6 +1057,8 @@ int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes) {
     if (!h || !blob_host) return YH_EINVAL;
     int rc = check_blob(h, (const uint8_t*)blob_host, nbytes);
     if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->dev));
+    if ((rc = keep_blob(h, blob_host, hipMemcpyHostToDevice))) return rc;
     return upload_panels(h, (const uint8_t*)blob_host);
 }
 
@@ -1053,7 +1070,127 @@ int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes) {
     HIPCHK(h, hipMemcpy(host.data(), blob_dev, nbytes, hipMemcpyDeviceToHost));
     int rc = check_blob(h, host.data(), nbytes);
     if (rc) return rc;
+    if ((rc = keep_blob(h, blob_dev, hipMemcpyDeviceToDevice))) return rc;
     return upload_panels(h, host.data());
+}
+
+// ---- multi-GPU: the path's ONE collective, behind the C ABI --------------------------------------------
+// SURVEY.md §8e / north_star: frames shard over the GPUs of a node with no per-step collective; the weights are
+// replicated once by an RCCL broadcast over xGMI. The reference's caller is a Rust process (src/main.rs:63-75),
+// not torch, so the broadcast lives here. librccl.so (573 MB) is opened on first use only; the symbols are
+// declared locally (rccl.h: ncclUniqueId = 128 opaque bytes, ncclUint8 = 1, ncclSuccess = 0).
+namespace {
+struct RcclId { char internal[YH_RCCL_ID_BYTES]; };
+typedef void* rccl_comm;
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(rccl_comm*, int, RcclId, int) = nullptr;
+    int (*CommInitAll)(rccl_comm*, int, const int*) = nullptr;
+    int (*CommDestroy)(rccl_comm) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl* rccl() {   // opened once per process; a failed open is remembered with its reason
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.err = std::string("dlopen librccl.so: ") + (dlerror() ? dlerror() : "not found"); return &r; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl.so lacks ") + n; return p; };
+    r.GetUniqueId = (int (*)(RcclId*))sym("ncclGetUniqueId");
+    r.CommInitRank = (int (*)(rccl_comm*, int, RcclId, int))sym("ncclCommInitRank");
+    r.CommInitAll = (int (*)(rccl_comm*, int, const int*))sym("ncclCommInitAll");
+    r.CommDestroy = (int (*)(rccl_comm))sym("ncclCommDestroy");
+    r.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t))sym("ncclBroadcast");
+    r.GroupStart = (int (*)())sym("ncclGroupStart");
+    r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    return &r;
+}
+std::string rccl_msg(Rccl* r, const char* what, int rc) { return std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "error") ; }
+// after the receive: validate and repack exactly as yh_load_weights_device does
+int adopt_received_blob(yh_engine* h) {
+    std::vector<uint8_t> host(h->blob_bytes);
+    HIPCHK(h, hipMemcpy(host.data(), h->blob_dev, h->blob_bytes, hipMemcpyDeviceToHost));
+    const int rc = check_blob(h, host.data(), h->blob_bytes);
+    if (rc) return rc;
+    return upload_panels(h, host.data());
+}
+}  // namespace
+
+int yh_rccl_unique_id(void* id_out) {
+    if (!id_out) return YH_EINVAL;
+    Rccl* r = rccl();
+    if (!r->err.empty()) { g_create_error = r->err; return YH_EHIP; }
+    RcclId id;
+    const int rc = r->GetUniqueId(&id);
+    if (rc) { g_create_error = rccl_msg(r, "ncclGetUniqueId", rc); return YH_EHIP; }
+    memcpy(id_out, &id, sizeof id);
+    return YH_OK;
+}
+
+int yh_rank_broadcast_weights(yh_engine* h, const void* id_bytes, int32_t rank, int32_t nranks, int32_t root) {
+    if (!h || !id_bytes) return YH_EINVAL;
+    if (nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks) return h->fail(YH_EINVAL, "rank / nranks / root out of range");
+    if (rank == root && !h->weights_loaded) return h->fail(YH_ESTATE, "the root rank must have its weights loaded before the broadcast");
+    Rccl* r = rccl();
+    if (!r->err.empty()) return h->fail(YH_EHIP, r->err);
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = rank == root ? YH_OK : keep_blob(h, h->blob_dev, hipMemcpyDeviceToDevice);   // non-root: allocate the receive buffer
+    if (rc) return rc;
+    RcclId id;
+    memcpy(&id, id_bytes, sizeof id);
+    rccl_comm comm = nullptr;
+    int e = r->CommInitRank(&comm, nranks, id, rank);
+    if (e) return h->fail(YH_EHIP, rccl_msg(r, "ncclCommInitRank", e));
+    e = r->Broadcast(h->blob_dev, h->blob_dev, h->blob_bytes, /*ncclUint8*/ 1, root, comm, h->stream);
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    r->CommDestroy(comm);
+    if (e) return h->fail(YH_EHIP, rccl_msg(r, "ncclBroadcast", e));
+    if (se != hipSuccess) return h->fail(YH_EHIP, std::string("weight broadcast: ") + hipGetErrorString(se));
+    return rank == root ? YH_OK : adopt_received_blob(h);
+}
+
+int yh_group_broadcast_weights(yh_engine** hs, int32_t n, int32_t root) {
+    if (!hs || n < 1 || root < 0 || root >= n) return YH_EINVAL;
+    for (int i = 0; i < n; ++i) if (!hs[i]) return YH_EINVAL;
+    yh_engine* h0 = hs[root];
+    if (!h0->weights_loaded) return h0->fail(YH_ESTATE, "the root handle must have its weights loaded before the broadcast");
+    for (int i = 0; i < n; ++i) {
+        if (hs[i]->blob_bytes != h0->blob_bytes) return h0->fail(YH_EINVAL, "handles of one group must share the architecture");
+        for (int j = 0; j < i; ++j) if (hs[j]->dev == hs[i]->dev) return h0->fail(YH_EINVAL, "one handle per device: RCCL refuses two ranks on one GPU");
+    }
+    if (n == 1) return YH_OK;
+    Rccl* r = rccl();
+    if (!r->err.empty()) return h0->fail(YH_EHIP, r->err);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        devs[i] = hs[i]->dev;
+        if (i != root) { HIPCHK(hs[i], hipSetDevice(hs[i]->dev)); const int rc = keep_blob(hs[i], hs[i]->blob_dev, hipMemcpyDeviceToDevice); if (rc) return rc; }
+    }
+    std::vector<rccl_comm> comms(n, nullptr);
+    int e = r->CommInitAll(comms.data(), n, devs.data());
+    if (e) return h0->fail(YH_EHIP, rccl_msg(r, "ncclCommInitAll", e));
+    e = r->GroupStart();   // one thread drives every device: the n broadcasts must be one group
+    for (int i = 0; i < n && !e; ++i) e = r->Broadcast(hs[i]->blob_dev, hs[i]->blob_dev, h0->blob_bytes, 1, root, comms[i], hs[i]->stream);
+    const int ge = r->GroupEnd();
+    if (!e) e = ge;
+    hipError_t se = hipSuccess;
+    for (int i = 0; i < n; ++i) { hipSetDevice(hs[i]->dev); const hipError_t s1 = hipStreamSynchronize(hs[i]->stream); if (se == hipSuccess) se = s1; }
+    for (rccl_comm c : comms) if (c) r->CommDestroy(c);
+    if (e) return h0->fail(YH_EHIP, rccl_msg(r, "ncclBroadcast (group)", e));
+    if (se != hipSuccess) return h0->fail(YH_EHIP, std::string("weight broadcast: ") + hipGetErrorString(se));
+    for (int i = 0; i < n; ++i)
+        if (i != root) { HIPCHK(hs[i], hipSetDevice(hs[i]->dev)); const int rc = adopt_received_blob(hs[i]); if (rc) return rc; }
+    return YH_OK;
 }
 
 int yh_input_dims(const yh_engine* h, int32_t dims[4]) {

@@ -73,9 +73,13 @@ SYMBOLS = [
     ("yh_get_tuning", _i, [_vp, C.POINTER(Tuning)]),
     ("yh_last_error", C.c_char_p, [_vp]),
     ("yh_weights_nbytes", _sz, [_vp]),
+    ("yh_weights_device_ptr", _vp, [_vp]),
     ("yh_weights_generate", _i, [_vp, C.c_uint64, _vp, _sz]),
     ("yh_load_weights_host", _i, [_vp, _vp, _sz]),
     ("yh_load_weights_device", _i, [_vp, _vp, _sz]),
+    ("yh_group_broadcast_weights", _i, [C.POINTER(_vp), _i, _i]),
+    ("yh_rccl_unique_id", _i, [_vp]),
+    ("yh_rank_broadcast_weights", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_input_dims", _i, [_vp, C.POINTER(_i * 4)]),
     ("yh_set_input_u8", _i, [_vp, _vp, _i]),
     ("yh_set_input_u8_device", _i, [_vp, _vp, _i]),
@@ -145,6 +149,25 @@ def load_library():
 
 def version():
     return load_library().yh_version().decode()
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (128 bytes) for yh_rank_broadcast_weights."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.yh_rccl_unique_id(buf)
+    if rc != OK:
+        raise YhError(rc, L.yh_last_error(None).decode())
+    return buf.raw
+
+
+def group_broadcast_weights(engines, root=0):
+    """One process, one Engine per GPU: RCCL broadcast of engines[root]'s weights to the others."""
+    L = load_library()
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    rc = L.yh_group_broadcast_weights(arr, len(engines), root)
+    if rc != OK:
+        raise YhError(rc, L.yh_last_error(engines[root].h).decode())
 
 
 def _p(a):
@@ -232,8 +255,16 @@ class Engine:
         blob = np.ascontiguousarray(blob, np.uint8)
         self._chk(self.L.yh_load_weights_host(self.h, _p(blob), blob.size))
 
+    def weights_device_ptr(self):
+        return self.L.yh_weights_device_ptr(self.h)
+
     def load_weights_device(self, dev_ptr, nbytes):
         self._chk(self.L.yh_load_weights_device(self.h, C.c_void_p(dev_ptr), nbytes))
+
+    def rank_broadcast_weights(self, id_bytes, rank, nranks, root=0):
+        """One process per GPU: RCCL broadcast of the root rank's weights (id_bytes from rccl_unique_id on one rank)."""
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        self._chk(self.L.yh_rank_broadcast_weights(self.h, buf, rank, nranks, root))
 
     # ---- interpreter-shaped surface
     def input_dims(self):
