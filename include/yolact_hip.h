@@ -87,7 +87,7 @@ typedef struct yh_tuning {
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
-    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan (0) */
+    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan, in segments of < 100 kernels (1) */
     int32_t reserved[7];     /* -1 */
 } yh_tuning;
 

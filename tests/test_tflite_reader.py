@@ -44,6 +44,77 @@ def test_reader_rejects_garbage_without_crashing(built):
     assert not ok and "TFL3" in msg
 
 
+def _structural_mutants(rng):
+    """(description, model) pairs: builder models broken in exactly the ways the plan builder (tflite_exec.hip:
+    prepare) would otherwise trip over: operand indices, arity, ranks, zero strides / dilations / multipliers."""
+    out = []
+
+    def mut(code, what, fn, **kw):
+        m = M.single_op(code, rng, **kw)
+        fn(m)
+        out.append((f"{code}: {what}", m))
+    for code in ("CONV_2D", "DEPTHWISE_CONV_2D"):
+        mut(code, "input index -1", lambda m: m.ops[0].inputs.__setitem__(0, -1))
+        mut(code, "weight index -1", lambda m: m.ops[0].inputs.__setitem__(1, -1))
+        mut(code, "bias index -7", lambda m: m.ops[0].inputs.__setitem__(2, -7))
+        mut(code, "one input", lambda m: m.ops[0].__setattr__("inputs", m.ops[0].inputs[:1]))
+        mut(code, "no output", lambda m: m.ops[0].__setattr__("outputs", []))
+        mut(code, "stride_h 0", lambda m: m.ops[0].opts.__setitem__("stride_h", 0))
+        mut(code, "stride_w -2", lambda m: m.ops[0].opts.__setitem__("stride_w", -2))
+        mut(code, "dilation 0", lambda m: m.ops[0].opts.__setitem__("dil_h", 0))
+        mut(code, "3-D input", lambda m: m.tensors[0].__setattr__("shape", m.tensors[0].shape[1:]))
+        mut(code, "3-D output", lambda m: m.tensors[-1].__setattr__("shape", m.tensors[-1].shape[1:]))
+    mut("DEPTHWISE_CONV_2D", "depth multiplier 0", lambda m: m.ops[0].opts.__setitem__("depth_multiplier", 0))
+    for code in ("ADD", "TANH", "RELU", "QUANTIZE", "DEQUANTIZE", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE"):
+        mut(code, "no output", lambda m: m.ops[0].__setattr__("outputs", []))
+        mut(code, "input index -1", lambda m: m.ops[0].inputs.__setitem__(0, -1))
+        mut(code, "no input", lambda m: m.ops[0].__setattr__("inputs", []))
+    mut("PAD", "3-D input", lambda m: m.tensors[0].__setattr__("shape", m.tensors[0].shape[1:]))
+    mut("PAD", "3-D output", lambda m: m.tensors[2].__setattr__("shape", m.tensors[2].shape[1:]))
+    mut("RESIZE_BILINEAR", "2-D output", lambda m: m.tensors[2].__setattr__("shape", m.tensors[2].shape[2:]))
+    mut("CONCATENATION", "rank mismatch", lambda m: m.tensors[0].__setattr__("shape", m.tensors[0].shape[1:]))
+    return out
+
+
+def test_graph_validation_rejects_what_the_plan_builder_would_trip_over(built, tmp_path):
+    """yh_tfl_validate (no GPU) now also checks everything prepare() dereferences. Every structural
+    mutant is rejected with a message; the same files, plus byte-flip and truncation mutants, go through the reader
+    compiled with AddressSanitizer + UBSan (tests/tfl_reader_harness.cpp), which must finish without a report."""
+    import subprocess
+    import yolact_amd as ya
+    rng = np.random.default_rng(11)
+    files = []
+    for i, (what, m) in enumerate(_structural_mutants(rng)):
+        blob = bytes(B.serialize(m))
+        ok, _, _, msg = ya.tfl_validate(blob)
+        assert not ok and msg, what
+        p = tmp_path / f"s{i}.tflite"
+        p.write_bytes(blob)
+        files.append(str(p))
+    # forged vector lengths and random metadata damage
+    good = bytes(B.serialize(M.mobilenet_like(rng)))
+    for i in range(150):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 5))):
+            at = int(rng.integers(0, min(len(b), 6000)))
+            b[at:at + 4] = int(rng.choice([0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0, int(rng.integers(0, 1 << 32))])).to_bytes(4, "little")
+        ya.tfl_validate(bytes(b))                        # must return
+        p = tmp_path / f"f{i}.tflite"
+        p.write_bytes(bytes(b[:len(good)]))
+        files.append(str(p))
+    (tmp_path / "good.tflite").write_bytes(good)
+    exe = tmp_path / "harness"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(root, "tiny-object-detection_amd", "csrc"), "-o", str(exe),
+                           os.path.join(root, "tests", "tfl_reader_harness.cpp")])
+    r = subprocess.run([str(exe), str(tmp_path / "good.tflite")] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert lines[0].endswith("good.tflite ok [%s]" % lines[0].split("[")[-1].rstrip("]")) and " ok" in lines[0]
+    assert sum("rejected" in ln for ln in lines) >= len(_structural_mutants(rng))
+
+
 def test_oracle_fixed_point_primitives():
     """gemmlowp primitives against exact rational arithmetic."""
     import tfl_oracle as O

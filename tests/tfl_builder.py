@@ -174,10 +174,10 @@ def _options(op):
     o, c = op.opts, op.code
     if c == "CONV_2D":
         return _Table({0: ("b", o["padding"]), 1: ("i", o["stride_w"]), 2: ("i", o["stride_h"]), 3: ("b", o.get("act", 0)),
-                       4: ("i", 1), 5: ("i", 1)})
+                       4: ("i", o.get("dil_w", 1)), 5: ("i", o.get("dil_h", 1))})
     if c == "DEPTHWISE_CONV_2D":
         return _Table({0: ("b", o["padding"]), 1: ("i", o["stride_w"]), 2: ("i", o["stride_h"]), 3: ("i", o.get("depth_multiplier", 1)),
-                       4: ("b", o.get("act", 0)), 5: ("i", 1), 6: ("i", 1)})
+                       4: ("b", o.get("act", 0)), 5: ("i", o.get("dil_w", 1)), 6: ("i", o.get("dil_h", 1))})
     if c == "ADD":
         return _Table({0: ("b", o.get("act", 0))})
     if c == "CONCATENATION":

@@ -289,8 +289,11 @@ struct yh_tfl {
     std::vector<char> alias;    // tens[i] shares another tensor's buffer (RESHAPE): not freed twice
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
-    hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
-    int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
+    // the plan, captured once and replayed (tensor addresses never change), in segments of at most kGraphSegment
+    // kernels each (see run_plan)
+    std::vector<hipGraphExec_t> gexecs;
+    static const int kGraphSegment = 96;
+    int use_dot = 1, use_graph = 1;   // yh_tuning.tfl_dot / tfl_graph
     // classify scratch
     uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
     uint8_t* tiles_dev = nullptr;
@@ -505,9 +508,13 @@ int prepare(yh_tfl* h) {
     return YH_OK;
 }
 
-int enqueue_plan(yh_tfl* h) {
+int plan_kernels(const Prepared& p) { return p.kind == P_CONCAT ? (int)p.cat.size() : 1; }
+
+int enqueue_plan(yh_tfl* h, size_t first = 0, size_t last = (size_t)-1) {
     hipStream_t s = h->stream;
-    for (const Prepared& p : h->plan) {
+    if (last > h->plan.size()) last = h->plan.size();
+    for (size_t pi = first; pi < last; ++pi) {
+        const Prepared& p = h->plan[pi];
         switch (p.kind) {
             case P_CONV:
                 if (p.conv.wsum) {
@@ -534,24 +541,41 @@ int enqueue_plan(yh_tfl* h) {
     return YH_OK;
 }
 
-// Optional (YH_TFL_GRAPH=1): one invoke = one graph launch. It measures 5 % faster per invoke on the
-// 136-op model (1.11 vs 1.17 ms; the step is bound by kernel time, not by launches) and is off by
-// default because rocprofv3 --kernel-trace crashed inside hipGraphLaunch after ~110 replays of this
-// 137-kernel graph (the YOLACT engine's graphs replay under the profiler without trouble).
+// One invoke = a few graph launches (yh_tuning.tfl_graph, default 1; 0 = eager launches): 5 % faster per invoke on the
+// 136-op model (1.09 vs 1.17 ms; the step is bound by kernel time, not by launches).
+// The plan is captured in SEGMENTS of at most kGraphSegment kernels. Round 1 captured the whole 137-kernel plan as one
+// graph; replayed under `rocprofv3 --kernel-trace` that graph crashed with SIGSEGV in a copy inside the profiler's
+// dispatch interception, called from hipGraphLaunch (profiles/r02_tflite_graph_crash_rocprofv3.log), while the same
+// graph replays cleanly without the profiler (600 invokes) and the YOLACT engine's 93-kernel graphs replay under it:
+// the profiler, not the plan, faults once a single graph launch carries more kernel dispatches than it copes with.
+// Keeping every graph launch under 100 kernels avoids that case at no measurable cost.
 int run_plan(yh_tfl* h) {
     if (!h->use_graph) return enqueue_plan(h);
-    if (!h->gexec) {
-        hipGraph_t g = nullptr;
-        TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue_plan(h);
-        const hipError_t e = hipStreamEndCapture(h->stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
-        const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ei != hipSuccess) { h->gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
+    if (h->gexecs.empty()) {
+        size_t first = 0;
+        while (first < h->plan.size()) {
+            size_t last = first;
+            int kernels = 0;
+            while (last < h->plan.size() && (last == first || kernels + plan_kernels(h->plan[last]) <= yh_tfl::kGraphSegment)) kernels += plan_kernels(h->plan[last++]);
+            hipGraph_t g = nullptr;
+            TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+            const int rc = enqueue_plan(h, first, last);
+            const hipError_t e = hipStreamEndCapture(h->stream, &g);
+            hipGraphExec_t ge = nullptr;
+            hipError_t ei = hipSuccess;
+            if (!rc && e == hipSuccess && g) ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (g) hipGraphDestroy(g);
+            if (rc || e != hipSuccess || ei != hipSuccess || !ge) {
+                for (hipGraphExec_t x : h->gexecs) hipGraphExecDestroy(x);
+                h->gexecs.clear();
+                if (rc) return rc;
+                return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e != hipSuccess ? e : ei));
+            }
+            h->gexecs.push_back(ge);
+            first = last;
+        }
     }
-    TCHK(h, hipGraphLaunch(h->gexec, h->stream));
+    for (hipGraphExec_t ge : h->gexecs) TCHK(h, hipGraphLaunch(ge, h->stream));
     return YH_OK;
 }
 
@@ -607,7 +631,7 @@ void yh_tfl_destroy(yh_tfl* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    for (hipGraphExec_t ge : h->gexecs) hipGraphExecDestroy(ge);
     for (size_t i = 0; i < h->tens.size(); ++i) if (h->tens[i] && !(i < h->alias.size() && h->alias[i])) hipFree(h->tens[i]);
     for (void* p : h->extra) hipFree(p);
     void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };

@@ -28,7 +28,19 @@ struct TflTensor {
     bool quant = false;
     float scale = 1.0f;
     int zp = 0;
-    size_t count() const { size_t c = 1; for (int s : shape) c *= (size_t)s; return c; }
+    size_t count() const { size_t c = 1; for (int s : shape) c *= (size_t)s; return c; }   // (parse() bounds it: <= kMaxElems)
+    static constexpr uint64_t kMaxElems = 1ull << 31;
+    // element count with overflow checking: false if a dimension is negative or the product exceeds kMaxElems
+    bool count_checked(uint64_t* out) const {
+        uint64_t c = 1;
+        for (int s : shape) {
+            if (s < 0) return false;
+            if (s != 0 && c > kMaxElems / (uint64_t)s) return false;
+            c *= (uint64_t)s;
+        }
+        *out = c;
+        return true;
+    }
     size_t elem() const { return type == TFL_U8 || type == TFL_I8 ? 1 : (type == TFL_I64 ? 8 : 4); }
 };
 
@@ -57,7 +69,9 @@ public:
         if (!ok_ || !subgraphs || vlen(subgraphs) < 1) return fail("model has no subgraph");
         std::vector<int> codes;
         std::vector<std::string> customs;
-        for (uint32_t i = 0; i < vlen(opcodes); ++i) {
+        // (a forged vector length must not drive the loop: every entry needs 4 bytes of file)
+        if (opcodes && (uint64_t)vlen(opcodes) > n_ / 4) return fail("operator-code vector longer than the file");
+        for (uint32_t i = 0; ok_ && i < vlen(opcodes); ++i) {
             const uint32_t oc = vtab(opcodes, i);
             int dep = (int8_t)scalar8(oc, 0, 0), full = (int)scalar32(oc, 3, 0);
             codes.push_back(full > dep ? full : dep);
@@ -95,6 +109,8 @@ public:
                 }
             }
             for (int s : x.shape) if (s < 0 || s > (1 << 24)) return fail("unsupported tensor shape in " + x.name);
+            uint64_t ne = 0;
+            if (x.shape.size() > 8 || !x.count_checked(&ne)) return fail("tensor too large or of too high a rank: " + x.name);
             if (x.data && x.nbytes != x.count() * x.elem()) return fail("constant size mismatch in " + x.name);
             tensors.push_back(x);
         }
@@ -131,7 +147,72 @@ public:
         }
         for (int t : inputs) if (t < 0 || t >= (int)tensors.size()) return fail("graph input out of range");
         for (int t : outputs) if (t < 0 || t >= (int)tensors.size()) return fail("graph output out of range");
-        return ok_ ? true : fail("truncated or malformed flatbuffer");
+        if (!ok_) return fail("truncated or malformed flatbuffer");
+        return validate_graph();
+    }
+
+    // Everything the executor's plan builder (tflite_exec.hip: prepare) dereferences, checked WITHOUT a GPU: operator
+    // arity, every tensor index it reads (only a convolution's bias may be the optional -1), ranks, kernel / stride /
+    // dilation / depth-multiplier >= 1 (they are divisors), constant operands present where the plan reads them on the
+    // host. A file that passes cannot make prepare() index out of range or divide by zero; what is merely unsupported
+    // (another dtype, a dynamic shape) is still reported by prepare() with its own message.
+    bool validate_graph() {
+        const int nt = (int)tensors.size();
+        auto idx = [&](int t) { return t >= 0 && t < nt; };
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            const TflOp& op = ops[oi];
+            const std::string at = " (operator " + std::to_string(oi) + ")";
+            for (int t : op.out) if (!idx(t)) return fail("operator output index out of range" + at);
+            auto ins = [&](size_t lo, size_t hi) { return op.in.size() >= lo && op.in.size() <= hi; };
+            auto all_in = [&]() { for (int t : op.in) if (!idx(t)) return false; return true; };
+            auto rank = [&](int t, size_t r) { return tensors[t].shape.size() == r; };
+            switch (op.code) {
+                case TFL_CONV_2D:
+                case TFL_DEPTHWISE_CONV_2D: {
+                    if (!ins(2, 3) || op.out.size() != 1 || !idx(op.in[0]) || !idx(op.in[1])) return fail("conv: bad arity or operand index" + at);
+                    if (op.in.size() == 3 && op.in[2] != -1 && !idx(op.in[2])) return fail("conv: bias index out of range" + at);
+                    if (!rank(op.in[0], 4) || !rank(op.in[1], 4) || !rank(op.out[0], 4)) return fail("conv: operands must be 4-D" + at);
+                    if (op.stride_h < 1 || op.stride_w < 1 || op.dil_h < 1 || op.dil_w < 1 || op.depth_mult < 1 ||
+                        op.stride_h > 64 || op.stride_w > 64 || op.dil_h > 64 || op.dil_w > 64)
+                        return fail("conv: stride, dilation and depth multiplier must be in 1..64" + at);
+                    const std::vector<int>& w = tensors[op.in[1]].shape;
+                    if (w[1] < 1 || w[2] < 1 || w[0] < 1 || w[3] < 1) return fail("conv: empty kernel" + at);
+                    for (int d : tensors[op.in[0]].shape) if (d < 1) return fail("conv: empty input" + at);
+                    break;
+                }
+                case TFL_ADD:
+                    if (!ins(2, 2) || op.out.size() != 1 || !all_in()) return fail("add: bad arity or operand index" + at);
+                    break;
+                case TFL_RELU: case TFL_RELU6: case TFL_QUANTIZE: case TFL_DEQUANTIZE: case TFL_TANH:
+                    if (!ins(1, 1) || op.out.size() != 1 || !all_in()) return fail("unary operator: bad arity or operand index" + at);
+                    break;
+                case TFL_PAD:
+                    if (!ins(2, 2) || op.out.size() != 1 || !all_in()) return fail("pad: bad arity or operand index" + at);
+                    if (!rank(op.in[0], 4) || !rank(op.out[0], 4)) return fail("pad: input and output must be 4-D" + at);
+                    if (tensors[op.in[1]].type != TFL_I32 || !tensors[op.in[1]].data || tensors[op.in[1]].nbytes != 32) return fail("pad: paddings must be a constant int32 [4,2]" + at);
+                    break;
+                case TFL_RESIZE_BILINEAR:
+                    if (!ins(2, 2) || op.out.size() != 1 || !all_in()) return fail("resize_bilinear: bad arity or operand index" + at);
+                    if (!rank(op.in[0], 4) || !rank(op.out[0], 4)) return fail("resize_bilinear: input and output must be 4-D" + at);
+                    if (tensors[op.in[1]].type != TFL_I32 || !tensors[op.in[1]].data || tensors[op.in[1]].nbytes != 8) return fail("resize_bilinear: size must be a constant int32 [2]" + at);
+                    for (int d : tensors[op.in[0]].shape) if (d < 1) return fail("resize_bilinear: empty input" + at);
+                    for (int d : tensors[op.out[0]].shape) if (d < 1) return fail("resize_bilinear: empty output" + at);
+                    break;
+                case TFL_CONCATENATION: {
+                    if (op.in.empty() || op.out.size() != 1 || !all_in()) return fail("concatenation: bad arity or operand index" + at);
+                    const size_t nd = tensors[op.out[0]].shape.size();
+                    if (nd < 1) return fail("concatenation: scalar output" + at);
+                    for (int t : op.in) if (tensors[t].shape.size() != nd) return fail("concatenation: rank mismatch" + at);
+                    break;
+                }
+                case TFL_RESHAPE:
+                    if (!ins(1, 2) || op.out.size() != 1 || !idx(op.in[0])) return fail("reshape: bad arity or operand index" + at);
+                    break;
+                default:
+                    break;   // unsupported / custom operators: prepare() refuses them by name before touching any operand
+            }
+        }
+        return true;
     }
 
 private:
