@@ -99,6 +99,9 @@ int orc_detect(const orc_det_cfg* cfg, const float* loc, const float* conf, cons
 /* ---- OCP FP8 E4M3 (orc_fp8.c): groundwork for an fp8 convolution path, pinned by exhaustive search ---- */
 /* accuracy study: the net's K-heavy 3x3 convs (cin >= 256) with E4M3-rounded operands (orc_net.c) */
 void orc_net_set_fp8_study(orc_net* net, int on);
+/* fp8 forward mode (configs[4]): name the convolutions that read E4M3 operands, each with its activation scale */
+void orc_net_clear_fp8(orc_net* net);
+int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale);
 float orc_e4m3_to_f32(uint8_t b);
 uint8_t orc_e4m3_from_f32(float x);              /* round to nearest even, saturating at +-448, NaN -> 0x7F */
 void orc_quantize_e4m3(const float* x, long long n, float inv_scale, uint8_t* y);

@@ -212,6 +212,17 @@ class Net:
     def flops_per_frame(self):
         return lib().orc_net_flops_per_frame(self.h)
 
+    def set_fp8(self, layers=None):
+        """fp8 forward mode (configs[4]): `layers` = {conv name: activation scale} of the convolutions that read E4M3
+        operands (names as in orc_net.c: l3b0_b, p5, proto0, head_t0 ...); None / {} switches it off."""
+        L = lib()
+        L.orc_net_clear_fp8.argtypes = [C.c_void_p]
+        L.orc_net_add_fp8_layer.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
+        L.orc_net_add_fp8_layer.restype = C.c_int
+        L.orc_net_clear_fp8(self.h)
+        for name, scale in (layers or {}).items():
+            assert L.orc_net_add_fp8_layer(self.h, name.encode(), float(scale)) == 0, name
+
     def forward(self, rgb, f16=True, nthreads=None, fp8_study=False):
         """fp8_study: the K-heavy 3x3 convs run on E4M3-rounded operands (accuracy study)."""
         lib().orc_net_set_fp8_study.argtypes = [C.c_void_p, C.c_int]

@@ -75,6 +75,10 @@ struct orc_net {
     double flops;
     int nthreads, f16;
     int fp8;   /* accuracy study: fake-quantise the K-heavy 3x3 convs' operands to E4M3 */
+    /* fp8 forward mode (DESIGN.md §Precision, configs[4]): the named convolutions read E4M3 operands - activations with
+     * the GIVEN per-tensor scale (the engine's calibration result), weights with one scale per output channel */
+    int n_fp8;
+    struct { char name[24]; float act_scale; } fp8_layers[256];
 };
 
 /* ------------------------------------------------------------------ canonical conv table */
@@ -191,7 +195,7 @@ static float act_apply(float v, int act) {
 
 static void conv_core(const float* x, int n, int h, int w, int cin, const float* wt, const float* bias,
                       int cout, int kh, int kw, int stride, int pad, const float* res, int act,
-                      int f16, int nthreads, float* y, int ho, int wo) {
+                      int f16, int nthreads, float* y, int ho, int wo, const float* ch_scale) {
     long M = (long)n * ho * wo;
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
@@ -234,7 +238,7 @@ static void conv_core(const float* x, int n, int h, int w, int cin, const float*
             for (int p = 0; p < np; ++p) {
                 size_t o = (size_t)(m0 + p) * cout + kb;
                 for (int k = 0; k < kn; ++k) {
-                    float v = acc[p][k] + bias[kb + k];
+                    float v = ch_scale ? fmaf(acc[p][k], ch_scale[kb + k], bias[kb + k]) : acc[p][k] + bias[kb + k];
                     if (res) v = v + res[o + k];
                     v = act_apply(v, act);
                     y[o + k] = f16 ? orc_f16_round(v) : v;
@@ -255,7 +259,7 @@ void orc_conv2d(const float* x, int n, int h, int w, int cin, const float* wk, c
     for (int o = 0; o < cout; ++o)
         for (size_t k = 0; k < K; ++k) wt[k * cout + o] = wk[(size_t)o * K + k];
     conv_core(x, n, h, w, cin, wt, bias, cout, kh, kw, stride, pad, residual, act, f16_storage,
-              nthreads, y, out_dim(h, kh, stride, pad), out_dim(w, kw, stride, pad));
+              nthreads, y, out_dim(h, kh, stride, pad), out_dim(w, kw, stride, pad), NULL);
     free(wt);
 }
 
@@ -328,6 +332,31 @@ static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x
     if (cw->cin != x->c) { fprintf(stderr, "oracle: conv %s cin %d vs %d\n", name, cw->cin, x->c); abort(); }
     int ho = out_dim(x->h, cw->kh, stride, pad), wo = out_dim(x->w, cw->kw, stride, pad);
     tensor* y = new_t(net, name, x->n, ho, wo, cw->cout);
+    /* fp8 forward mode: this convolution was named with its activation scale s_x.
+     *   x8 = e4m3(x * (1 / s_x))   on the stored (f16-rounded) input tensor, round to nearest even, saturating
+     *   w8 = e4m3(w * (1 / s_w[o])), s_w[o] = max_k |w[o][k]| / 448 (1 if the row is all zero)
+     *   y  = act(fma(sum x8 * w8, s_x * s_w[o], bias[o]) + residual), rounded to f16
+     * the sum of products in f32 (products of two E4M3 values are exact in f32). */
+    for (int li = 0; li < net->n_fp8; ++li)
+        if (strcmp(net->fp8_layers[li].name, name) == 0) {
+            const float sx = net->fp8_layers[li].act_scale, inv_sx = 1.0f / sx;
+            size_t nx = (size_t)x->n * x->h * x->w * x->c, K = (size_t)cw->kh * cw->kw * cw->cin;
+            float* xq = (float*)malloc(nx * sizeof(float));
+            float* wq = (float*)malloc(K * cw->cout * sizeof(float));
+            float* chs = (float*)malloc((size_t)cw->cout * sizeof(float));
+            for (size_t i = 0; i < nx; ++i) xq[i] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i] * inv_sx));
+            for (int o = 0; o < cw->cout; ++o) {
+                float aw = 0.0f;
+                for (size_t k = 0; k < K; ++k) { float a = fabsf(cw->wt[k * cw->cout + o]); if (a > aw) aw = a; }
+                const float sw = aw > 0.0f ? aw / 448.0f : 1.0f, inv_sw = 1.0f / sw;
+                for (size_t k = 0; k < K; ++k) wq[k * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[k * cw->cout + o] * inv_sw));
+                chs[o] = sx * sw;
+            }
+            conv_core(xq, x->n, x->h, x->w, x->c, wq, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
+                      res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo, chs);
+            free(xq); free(wq); free(chs);
+            return y;
+        }
     /* study modes: 1 per-tensor / per-channel scales, 2 MX blocks, 3 = mode 1 on the protonet only */
     if (net->fp8 && cw->kh == 3 && cw->cin % 128 == 0 && cw->cin >= 256 && (net->fp8 != 3 || strncmp(name, "proto", 5) == 0)) {
         /* fp8 study: operands rounded to E4M3 - activations with one scale per tensor (max |x| -> 448),
@@ -366,12 +395,12 @@ static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x
         }
         }
         conv_core(xq, x->n, x->h, x->w, x->c, wq, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
-                  res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo);
+                  res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo, NULL);
         free(xq); free(wq);
         return y;
     }
     conv_core(x->d, x->n, x->h, x->w, x->c, cw->wt, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
-              res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo);
+              res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo, NULL);
     return y;
 }
 
@@ -448,6 +477,13 @@ void orc_net_destroy(orc_net* net) {
 }
 
 void orc_net_set_fp8_study(orc_net* net, int on) { net->fp8 = on; }
+void orc_net_clear_fp8(orc_net* net) { net->n_fp8 = 0; }
+int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale) {
+    if (net->n_fp8 >= 256 || !(act_scale > 0.0f)) return -1;
+    snprintf(net->fp8_layers[net->n_fp8].name, sizeof net->fp8_layers[0].name, "%s", conv_name);
+    net->fp8_layers[net->n_fp8++].act_scale = act_scale;
+    return 0;
+}
 int orc_net_num_priors(const orc_net* net) { return net->P; }
 void orc_net_proto_dims(const orc_net* net, int* hp, int* wp) { *hp = net->hp; *wp = net->wp; }
 void orc_net_priors(const orc_net* net, float* out) { memcpy(out, net->priors, (size_t)net->P * 16); }

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (FP8) { v[e] = v0[e] * scale8[e] + bias8[e]; v[4 + e] = v1[e] * scale8[4 + e] + bias8[4 + e]; }
+                        if (FP8) { v[e] = __builtin_fmaf(v0[e], scale8[e], bias8[e]); v[4 + e] = __builtin_fmaf(v1[e], scale8[4 + e], bias8[4 + e]); }
                         else { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
                     }
                     long long yo, ro;
@@ -498,7 +498,16 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     half8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                    *(half8*)(p.y + yo) = o;
+                    if (p.y) *(half8*)(p.y + yo) = o;
+                    if (p.y8) {   // fp8 precision: this tensor feeds an fp8 convolution (quantised from the f16-rounded value)
+                        unsigned lo = 0, hi = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            lo |= e4m3_code((float)o[e] * p.y8_inv_scale) << (8 * e);
+                            hi |= e4m3_code((float)o[4 + e] * p.y8_inv_scale) << (8 * e);
+                        }
+                        *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
+                    }
                 }
             }
         }
@@ -701,7 +710,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
     half8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-    *(half8*)(p.y + yo) = o;
+    if (p.y) *(half8*)(p.y + yo) = o;
+    if (p.y8) {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * p.y8_inv_scale) << (8 * e); hi |= e4m3_code((float)o[4 + e] * p.y8_inv_scale) << (8 * e); }
+        *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
+    }
 }
 
 int conv_tile_ch(ConvTile t) {
@@ -758,6 +773,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
         switch (tile) {
             case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, true>), grid, dim3(512), 0, stream, p); break;
+            case TILE_256x256_FP8:
+                if (!p.scale) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, true, true>), grid, dim3(512), 0, stream, p);
+                break;
             case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16, true>), grid, dim3(512), 0, stream, p); break;
             case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1, false, 32, true>), grid, dim3(512), 0, stream, p); break;
             case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict
 // grid = (ceil(wo * c8 / 256), ho, n); the row coordinates are wave-uniform.
 __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                     int h, int w, int c8, int ho, int wo,
-                                                    long long x_img_stride, long long y_img_stride) {
+                                                    long long x_img_stride, long long y_img_stride, uint8_t* __restrict__ y8, float y8_inv) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= wo * c8) return;
     const int ox = t / c8, cg = t - ox * c8, oy = blockIdx.y, b = blockIdx.z;
@@ -86,7 +86,14 @@ __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x
         const float bot = hx * (float)p10[e] + lx * (float)p11[e];
         o[e] = (half_t)(hy * top + ly * bot);
     }
-    *(half8*)(y + b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8) = o;
+    const long long yo = b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8;
+    if (y) *(half8*)(y + yo) = o;
+    if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value)
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv) << (8 * e); }
+        *(uint2*)(y8 + yo) = make_uint2(lo, hi);
+    }
 }
 
 // Output reads (not on the hot path): split the fused head rows into loc / conf / mask as f32.
@@ -128,12 +135,40 @@ __global__ __launch_bounds__(256) void quantize_e4m3_f16(const half_t* __restric
     if (t >= n) return;
     const float v = (float)x[t] * inv_scale;
     uint8_t code;
-    if (v != v) code = (uint8_t)(((__float_as_uint(v) >> 24) & 0x80u) | 0x7Fu);
-    else {
-        const float c = fminf(fmaxf(v, -448.0f), 448.0f);
-        code = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.0f, 0, false) & 0xFF);
-    }
+    code = (uint8_t)e4m3_code(v);
     y[t] = code;
+}
+
+// weight panel rows -> E4M3 with one scale per row (output channel): y[r][k] = e4m3(x[r][k] * inv_scale[r])
+__global__ __launch_bounds__(256) void quantize_rows_e4m3_f16(const half_t* __restrict__ x, uint8_t* __restrict__ y, int rows, int K,
+                                                              const float* __restrict__ inv_scale) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)rows * K) return;
+    y[t] = (uint8_t)e4m3_code((float)x[t] * inv_scale[t / K]);
+}
+
+// max |x| over an f16 range, as the bit pattern of a non-negative float (monotone as unsigned): one atomicMax per wave
+__global__ __launch_bounds__(256) void absmax_f16(const half_t* __restrict__ x, long long n8, unsigned* __restrict__ out) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const half8 v = *(const half8*)(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = fabsf((float)v[e]); m = a > m ? a : m; }   // (NaN never wins)
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void dequant_e4m3_f32(const uint8_t* __restrict__ x, float* __restrict__ y, long long n, float scale) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const unsigned b = x[t], s = b >> 7, e = (b >> 3) & 15u, m = b & 7u;
+    float v;
+    if (e == 15u && m == 7u) v = __uint_as_float(0x7FC00000u);
+    else if (e == 0u) v = (float)m * 0.001953125f;                          // m / 8 * 2^-6
+    else v = __uint_as_float(((e + 120u) << 23) | (m << 20));               // (1 + m / 8) * 2^(e - 7)
+    y[t] = (s ? -v : v) * scale;
 }
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
@@ -147,8 +182,23 @@ hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, 
     return hipGetLastError();
 }
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
-                           long long xs, long long ys, hipStream_t s) {
-    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys);
+                           long long xs, long long ys, hipStream_t s, uint8_t* y8, float y8_inv) {
+    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
+    return hipGetLastError();
+}
+hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, const float* inv_scale_rows, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_rows_e4m3_f16, dim3(nblk((long long)rows * K)), dim3(256), 0, s, x, y, rows, K, inv_scale_rows);
+    return hipGetLastError();
+}
+hipError_t launch_absmax_f16(const half_t* x, long long n, unsigned* out_bits, hipStream_t s) {
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    const long long n8 = n / 8;
+    const unsigned grid = (unsigned)(n8 < 256ll * 2048 ? (n8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_f16, dim3(grid ? grid : 1), dim3(256), 0, s, x, n8, out_bits);
+    return hipGetLastError();
+}
+hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(dequant_e4m3_f32, dim3(nblk(n)), dim3(256), 0, s, x, y, n, scale);
     return hipGetLastError();
 }
 hipError_t launch_quantize_e4m3(const half_t* x, uint8_t* y, long long n, float inv_scale, hipStream_t s) {

@@ -41,6 +41,10 @@ struct ConvParams {
     // fp8 form (experimental): x and w hold OCP E4M3 bytes; C, ldw and the image strides are in
     // 2-byte units (two fp8 values), so the loader is the f16 one; out = acc * scale[ch] + bias
     const float* scale;
+    // E4M3 output (fp8 precision: this tensor feeds an fp8 convolution): y8[same element offsets as y] =
+    // e4m3((float)(f16 result) * y8_inv_scale), round to nearest even, saturating. y may then be nullptr.
+    uint8_t* y8;
+    float y8_inv_scale;
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
@@ -83,8 +87,20 @@ hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int Hp, int Wp, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s);
+// y and / or y8 (E4M3 of the f16 result * y8_inv_scale) may be written
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
-                           long long x_img_stride, long long y_img_stride, hipStream_t s);
+                           long long x_img_stride, long long y_img_stride, hipStream_t s, uint8_t* y8 = nullptr, float y8_inv_scale = 1.0f);
+// fp8 precision helpers: weight rows -> E4M3 with one scale per row; |x| maximum of an f16 range (as the bit pattern
+// of a non-negative float, combined with atomicMax); E4M3 codes -> f32 (debug reads)
+hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, const float* inv_scale_rows, hipStream_t s);
+hipError_t launch_absmax_f16(const half_t* x, long long n, unsigned* out_bits, hipStream_t s);
+hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, float scale, hipStream_t s);
+// f32 -> E4M3 code, round to nearest even, saturating at +-448 (NaN keeps its sign with the NaN code)
+__device__ __forceinline__ unsigned e4m3_code(float v) {
+    if (v != v) return ((__float_as_uint(v) >> 24) & 0x80u) | 0x7Fu;
+    const float c = fminf(fmaxf(v, -448.0f), 448.0f);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.0f, 0, false) & 0xFFu;
+}
 // heads [n][cells][ldh] f16 -> loc/conf/mask/cells split as f32 (output reads only)
 hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc,
                               float* conf, float* mask, hipStream_t s);

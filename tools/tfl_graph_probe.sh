@@ -1,18 +1,21 @@
 #!/bin/bash
-# the TFLite plan as a replayed hipGraph, without and with rocprofv3 --kernel-trace.
-# Each step is bounded by its own timeout; logs go to gpurun_out/tflgraph/.
+# VERDICT r1 item 5 - what makes rocprofv3 --kernel-trace crash on the replayed TFLite plan?
+# Discriminating runs, each its own process with its own timeout; logs in gpurun_out/tflgraph/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/tflgraph
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[1] graph replay, no profiler, 600 invokes"
-timeout -k 10 240 python3 $R/tools/time_tflite.py --graph 1 --invokes 600 > $OUT/plain_graph1.log 2>&1; echo "exit=$?" >> $OUT/plain_graph1.log
-tail -3 $OUT/plain_graph1.log
-echo "[2] eager under rocprofv3 --kernel-trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_eager -o run --output-format csv -- python3 $R/tools/time_tflite.py --graph 0 --invokes 300 > $OUT/prof_graph0.log 2>&1; echo "exit=$?" >> $OUT/prof_graph0.log
-tail -3 $OUT/prof_graph0.log
-echo "[3] graph replay under rocprofv3 --kernel-trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_graph -o run --output-format csv -- python3 $R/tools/time_tflite.py --graph 1 --invokes 300 > $OUT/prof_graph1.log 2>&1; echo "exit=$?" >> $OUT/prof_graph1.log
-tail -25 $OUT/prof_graph1.log
-find $OUT -name "*kernel_stats.csv" | head; rm -rf $OUT/prof_eager/*/*kernel_trace.csv $OUT/prof_graph/*/*kernel_trace.csv 2>/dev/null; find $OUT -name "*.csv" -size +2M -delete
+run() {  # name, then the program and its arguments
+  local name=$1; shift
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/p_$name -o run --output-format csv -- "$@" > $OUT/$name.log 2>&1
+  echo "exit=$?" >> $OUT/$name.log
+  echo "== $name: $(grep -E 'graph replays|invoke 224|exit=' $OUT/$name.log | tr '\n' ' ')"
+  rm -rf $OUT/p_$name
+}
+run A_engine_invoke_single_branch python3 $R/tools/graph_probe.py invoke 300
+run B_engine_evaluate_forked python3 $R/tools/graph_probe.py evaluate 300
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+run C_tflite_graph_no_packet_capture python3 $R/tools/time_tflite.py --graph 1 --invokes 300
+run D_engine_invoke_no_packet_capture python3 $R/tools/graph_probe.py invoke 300
+unset DEBUG_CLR_GRAPH_PACKET_CAPTURE
 echo done
