@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tiny-object-detection_amd"))
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16
+MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0   # same guide: ~5 PF dense fp8 (block-scaled MFMA)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -135,8 +136,8 @@ def roofline_of(prof, batch=None):
     total_ms = sum(p["ms"] for p in prof)
     if d["flops"] > 0:
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        r = dict(bound="mfma", achieved=round(achieved, 2), peak=MFMA_F16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
-                 frac=round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), traffic=None)
+        peak = MFMA_FP8_DENSE_PEAK_TFLOPS if sym.startswith("conv_igemm_fp8") else MFMA_F16_DENSE_PEAK_TFLOPS   # the kernel's own dtype
+        r = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None)
     else:
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         r = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -331,7 +332,7 @@ def torch_cpu_forward(torch, convs, frames_u8, backbone=50):
     return torch.cat(loc, 1), torch.cat(cf, 1), torch.cat(mk, 1), proto.permute(0, 2, 3, 1).contiguous()
 
 
-def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, backbone=50):
+def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, backbone=50, fp8_layers=None):
     """The CPU oracle ("port": oracle/orc_net.c + orc_detect.c, the checker, never the product) timed on ALL of
     this host's cores on a bounded sample of the same workload: whole frames (forward + tail) until ~budget_s
     seconds have elapsed; beside it one frame at the reference's 4 threads (src/yolact.rs:34), one at 16, and a
@@ -386,13 +387,28 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, ba
                               max_abs_diff_vs_oracle_f32=[round(float(np.abs(a.numpy() - b).max()), 6) for a, b in zip(th, f32)])
     except Exception as e:   # noqa: BLE001 - reported in the line, never fatal for the GPU measurement
         r["torch_cpu"] = dict(error=str(e)[:200])
-    if eng_out is not None:
+    if eng_out is not None and not fp8_layers:
         r["engine_vs_oracle_same_frame"] = accuracy_vs_oracle(eng_out, first)
+    elif eng_out is not None:
+        # configs[4]: the engine ran its fp8 form; the oracle's fp8 mode with the engine's calibrated scales is its
+        # checker, and the gap to the f16 oracle is a reported property of the configuration
+        r["engine_fp8_vs_oracle_f16_same_frame"] = accuracy_vs_oracle(eng_out, first)
+        lay = {}
+        for name, sc in fp8_layers:
+            for nm in ([f"{name}{l}" for l in range(5)] if name in ("head_t", "head_out") else [name]):
+                lay[nm] = sc
+        net.set_fp8(lay)
+        h8 = net.forward(frames_u8[:1], f16=True, nthreads=cores)
+        net.set_fp8(None)
+        r["engine_vs_oracle_same_frame"] = accuracy_vs_oracle(eng_out, O.detect(h8[0][0], h8[1][0], h8[2][0], h8[3][0], pri))
+        r["engine_vs_oracle_same_frame"]["oracle_mode"] = f"fp8 forward mode, {len(fp8_layers)} E4M3 layers, the engine's calibrated scales"
     return r
 
 
-def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50):
-    eng = ya.Engine(input_size=size, backbone=backbone, max_batch=batch, use_graph=True, device=local_rank)
+def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50,
+               precision="f16"):
+    eng = ya.Engine(input_size=size, backbone=backbone, max_batch=batch, use_graph=True, device=local_rank,
+                    precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16)
     eng.load_weights_device(blob_dev_ptr, blob_nbytes)
     g = torch.Generator(device=f"cuda:{local_rank}")
     start, _ = shard_frames(world * batch, world, rank)
@@ -400,6 +416,10 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
     bufs = [torch.randint(0, 256, (batch, size, size, 3), dtype=torch.uint8, device=f"cuda:{local_rank}", generator=g)
             for _ in range(ring)]
     torch.cuda.synchronize()
+    if precision == "fp8":   # per-tensor activation scales from the bench frames themselves (outside the timed region)
+        eng.set_input_device(bufs[0].data_ptr(), batch)
+        eng.fp8_calibrate()
+        eng.sync()
 
     def step(i):
         eng.set_input_device(bufs[i % ring].data_ptr(), batch)
@@ -431,6 +451,7 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
             aux["host_to_detections_latency"] = host_to_detections_latency(eng, host)
         eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
         aux["dets_frame0"] = eng.detections(0, want_masks=True)
+        aux["fp8_layers"] = eng.fp8_layers() if precision == "fp8" else None
     if dist is not None:
         dist.barrier()
     eng.close()
@@ -445,6 +466,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (64: configs[2]/[3]; 1: configs[1])")
     ap.add_argument("--size", type=int, default=550)
     ap.add_argument("--backbone", type=int, default=50, choices=(50, 101), help="50: YOLACT-550 R50 (default); 101 with --size 700: configs[4] geometry in f16")
+    ap.add_argument("--precision", default="f16", choices=("f16", "fp8"),
+                    help="fp8: E4M3 operands on the block-scaled fp8 MFMA for the K-heavy 3x3 layers (configs[4]: --backbone 101 --size 700 --precision fp8)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -481,14 +504,14 @@ def main():
     blob_ptr = src.weights_device_ptr()
 
     dt, prof, flops, ndet, aux = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
-                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone)
+                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone, precision=a.precision)
     extra = {}
     if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
         s1 = max(a.steps * 4, 40)
         dt1, prof1, _, _, aux1 = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
-                                         blob_ptr, nbytes, backbone=a.backbone)
+                                         blob_ptr, nbytes, backbone=a.backbone, precision=a.precision)
         if rank == 0:
-            extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 fp16 {a.size}x{a.size}x3 per GPU (configs[1])",
+            extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 {a.precision} {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
                                    latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"],
@@ -500,24 +523,25 @@ def main():
         return
     fps = world * a.batch * a.steps / dt
     line = {
-        "metric": f"frames/sec YOLACT-{a.size} (ResNet-{a.backbone}-FPN, 32 prototypes) fp16, forward + detection tail",
+        "metric": f"frames/sec YOLACT-{a.size} (ResNet-{a.backbone}-FPN, 32 prototypes) " + ("fp16" if a.precision == "f16" else "fp8 (E4M3 operands on the K-heavy 3x3 layers, f16 elsewhere)") + ", forward + detection tail",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": f"YOLACT-{a.size} R{a.backbone}-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, "
                                f"hipGraph steady state, frames sharded over {world} GPU(s), weights replicated by one RCCL broadcast",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [a.size, a.size, 3],
                    "weights": f"seeded synthetic (seed {a.seed}), BN folded", "weights_replication": how,
                    "detections_first_frames": ndet},
         "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
-        "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),
+        "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),   # against the f16 peak in either precision (mixed-precision step)
         "roofline": roofline_of(prof, a.batch),
         "latency": aux["latency"],
         "pcie_inclusive_fps": aux["pcie_inclusive_fps"],
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"], backbone=a.backbone)
+        line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"], backbone=a.backbone,
+                                            fp8_layers=aux.get("fp8_layers"))
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

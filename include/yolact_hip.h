@@ -87,8 +87,10 @@ typedef struct yh_tuning {
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
-    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan, in segments of < 100 kernels (1) */
-    int32_t reserved[7];     /* -1 */
+    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan (1) */
+    int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0: one stream,
+                              * so the captured step is a single-branch graph */
+    int32_t reserved[6];     /* -1 */
 } yh_tuning;
 
 typedef struct yh_config {
@@ -165,6 +167,18 @@ int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes);
 /* Same, blob already in device memory on this handle's device (e.g. the receive buffer of an RCCL
  * broadcast from rank 0 over xGMI: SURVEY.md §8e). */
 int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
+
+/* ---- fp8 precision (yh_config.precision = YH_PRECISION_FP8; BASELINE.json configs[4]) -------------------------
+ * The K-heavy 3x3 convolutions read OCP E4M3 operands on the block-scaled fp8 MFMA: weights with one scale per
+ * output channel (fixed when the weights are loaded), activations with one scale per tensor, which must be set
+ * before the first invoke - by calibration on representative frames, or layer by layer from stored values. */
+/* Runs the f16 forward of the frames last set and sets every fp8 input tensor's scale to max|x| / 448. */
+int yh_fp8_calibrate(yh_engine* h);
+/* The convolutions that read E4M3 operands, in execution order: layer name (DESIGN.md layer names: "l3b0_b", "p5",
+ * "proto0", "head_t" ...) and the activation scale of its input tensor. */
+int yh_fp8_layer_count(const yh_engine* h);
+int yh_fp8_layer_info(const yh_engine* h, int32_t i, const char** conv_name, float* act_scale);
+int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale);
 
 /* ---- multi-GPU: the path's one collective (north_star: "weights replicated once via RCCL
  * broadcast over xGMI, no per-step collectives"). The reference's caller is a Rust process (src/main.rs:63-75,

@@ -40,6 +40,12 @@ struct Panel {             // device-side repacked weights of one launched conv
     int cout = 0, coutPad = 0, Kpad = 0, cin_store = 0, k = 0;
     ConvTile tile = TILE_128x128;
     std::vector<int> src;  // canonical conv indices concatenated along cout
+    // fp8 precision: the same weights as E4M3 codes, one scale per output channel
+    bool fp8 = false;
+    uint8_t* w8 = nullptr;     // [coutPad][Kpad] E4M3
+    float* scale = nullptr;    // [coutPad]: s_x (input tensor) * s_w[ch], refreshed by the calibration
+    std::vector<float> sw;     // [coutPad] weight scales (host)
+    int in_sid = -1;           // scale id of the input tensor these weights are applied to
 };
 
 struct Buf {               // dense NHWC f16 tensor [max_batch][h][w][c] or a slice of one
@@ -47,6 +53,10 @@ struct Buf {               // dense NHWC f16 tensor [max_batch][h][w][c] or a sl
     int h = 0, w = 0, c = 0;       // c = row stride in elements
     long long img_stride = 0;      // elements per image
     half_t* zero = nullptr;        // 16-byte zero block at the end of the owning allocation
+    // fp8 precision: the same tensor as E4M3 codes (same element offsets, one byte each), the allocation's scale id
+    uint8_t* q = nullptr;
+    uint8_t* qzero = nullptr;
+    int sid = -1;
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_BILINEAR, OP_STEMPOOL };
@@ -62,6 +72,8 @@ struct Op {
     int P = 0, Q = 0;      // output spatial
     int nlev = 0, lev_start[5] = {0, 0, 0, 0, 0}, lev_h[5] = {0, 0, 0, 0, 0}, lev_w[5] = {0, 0, 0, 0, 0};   // multi-level input (ConvParams)
     double flops_per_img = 0, bytes_per_img = 0, bytes_fixed = 0;
+    // fp8 precision: this conv reads E4M3 operands; what its output is written as (decided by who reads it)
+    bool fp8 = false, write_q = false, write_f16 = true;
 };
 
 size_t pad16(size_t v) { return (v + 15u) & ~(size_t)15u; }
@@ -90,7 +102,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -101,6 +113,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
+    r.tailfork = d(t.tailfork, 1);
     return r;
 }
 
@@ -125,6 +138,15 @@ struct yh_engine {
     std::vector<void*> allocs;
     std::map<std::string, Buf> named;
     std::set<std::string> fused_away;   // named tensors that production runs never write (debug_tensors = 1 materialises them)
+    // fp8 precision (yh_config.precision): per-allocation activation scales, filled by yh_fp8_calibrate
+    std::vector<float> act_scale;       // by Buf::sid
+    std::vector<half_t*> alloc_base;    // first element of allocation sid
+    std::vector<long long> alloc_img;   // elements per image of allocation sid
+    std::vector<int> fp8_ops;           // indices of the ops that read E4M3 operands
+    std::set<std::string> q_only;       // named tensors that exist only as E4M3 while fp8 is active
+    bool fp8_active = false;            // the op list currently runs its fp8 form (false during calibration and in f16 engines)
+    bool fp8_ready = false;             // scales calibrated
+    unsigned* absmax_dev = nullptr;
 
     uint8_t* in_u8 = nullptr;
     int in_hp = 0;
@@ -192,6 +214,16 @@ int new_buf(yh_engine* h, const char* name, int hh, int ww, int c, Buf* out) {
     if (hipMemset(p, 0, data_bytes + 256) != hipSuccess) return h->fail(YH_EHIP, "hipMemset arena");
     b.d = (half_t*)p;
     b.zero = (half_t*)((char*)p + ((data_bytes + 15) & ~(size_t)15));
+    b.sid = (int)h->act_scale.size();
+    h->act_scale.push_back(1.0f); h->alloc_base.push_back(b.d); h->alloc_img.push_back(b.img_stride);
+    if (h->cfg.precision == YH_PRECISION_FP8) {   // the E4M3 twin (288 GB of HBM: no aliasing games)
+        const size_t qbytes = data_bytes / 2;
+        rc = dev_alloc(h, &p, qbytes + 256);
+        if (rc) return rc;
+        if (hipMemset(p, 0, qbytes + 256) != hipSuccess) return h->fail(YH_EHIP, "hipMemset arena");
+        b.q = (uint8_t*)p;
+        b.qzero = b.q + ((qbytes + 15) & ~(size_t)15);
+    }
     if (name) h->named[name] = b;
     *out = b;
     return YH_OK;
@@ -378,6 +410,7 @@ int build_graph_spec(yh_engine* h) {
     auto level = [&](const Buf& base, int l) {
         Buf b = base;
         b.d = base.d + (long long)h->lvl_off[l] * base.c;
+        if (base.q) b.q = base.q + (long long)h->lvl_off[l] * base.c;
         b.h = b.w = h->lvl[l];
         return b;
     };
@@ -468,6 +501,59 @@ int build_graph_spec(yh_engine* h) {
     h->flops_per_frame = 0;
     for (const Op& o : h->ops) h->flops_per_frame += o.flops_per_img;
     return YH_OK;
+}
+
+// fp8 precision: which convolutions read E4M3 operands, and what each producer therefore writes.
+// Rule: 3x3 convolutions with >= 256 input channels (a multiple of 128: one 128-byte LDS row is
+// one K step of the block-scaled MFMA) and a multiple of 256 output channels (the fp8 kernel's tile). Everything else
+// stays f16. A tensor read only by fp8 convolutions is stored only as E4M3; one with both kinds of reader (the FPN
+// laterals: pred conv and bilinear upsample) is written in both forms by its producer's epilogue.
+void plan_fp8(yh_engine* h) {
+    struct Range { int sid; long long off, len; };
+    auto range = [&](const Buf& b) { return Range{ b.sid, (long long)(b.d - h->alloc_base[b.sid]), (long long)b.h * b.w * b.c }; };
+    auto overlap = [](const Range& a, const Range& b) { return a.sid == b.sid && a.off < b.off + b.len && b.off < a.off + a.len; };
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        Op& o = h->ops[i];
+        if (o.kind != OP_CONV) continue;
+        Panel& pn = h->panels[o.panel];
+        const ConvDesc& d0 = h->convs[pn.src[0]];
+        if (pn.k == 3 && d0.cin % 128 == 0 && d0.cin >= 256 && pn.cout % 256 == 0 && pn.coutPad % 256 == 0 && o.in.q) {
+            o.fp8 = true; pn.fp8 = true; pn.in_sid = o.in.sid;
+            h->fp8_ops.push_back((int)i);
+        }
+    }
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        Op& o = h->ops[i];
+        if (o.kind == OP_PRE) continue;
+        const Range w = range(o.out);
+        bool need_q = false, need_f16 = h->cfg.debug_tensors != 0;
+        for (size_t j = i + 1; j < h->ops.size(); ++j) {
+            const Op& c = h->ops[j];
+            if (c.kind == OP_PRE) continue;
+            if (overlap(w, range(c.in))) { if (c.fp8) need_q = true; else need_f16 = true; }
+            if (c.has_res && c.kind == OP_CONV && overlap(w, range(c.res))) need_f16 = true;
+        }
+        if (overlap(w, range(h->heads)) || overlap(w, range(h->proto))) need_f16 = true;   // engine outputs, read by the tail
+        if (!need_q && !need_f16) need_f16 = true;
+        o.write_q = need_q; o.write_f16 = need_f16;
+    }
+    // accounting (profile / roofline): E4M3 operands are one byte
+    for (Op& o : h->ops) {
+        if (o.kind != OP_CONV && o.kind != OP_BILINEAR) continue;
+        const double out_b = (o.write_f16 ? 2.0 : 0.0) + (o.write_q ? 1.0 : 0.0);
+        if (o.kind == OP_BILINEAR) { o.bytes_per_img = 2.0 * o.in.c * (double)o.in.h * o.in.w + out_b * o.in.c * (double)o.out.h * o.out.w; continue; }
+        const Panel& pn = h->panels[o.panel];
+        const ConvDesc& d0 = h->convs[pn.src[0]];
+        const double K = (double)pn.k * pn.k * d0.cin, in_elems = o.nlev ? (double)h->cells * d0.cin : (double)o.in.h * o.in.w * d0.cin;
+        o.bytes_per_img = (o.fp8 ? 1.0 : 2.0) * in_elems + (double)o.P * o.Q * pn.cout * (out_b + (o.has_res ? 2.0 : 0.0));
+        o.bytes_fixed = (o.fp8 ? 1.0 : 2.0) * pn.cout * K;
+        if (o.fp8) o.label = std::string(conv_tile_symbol(TILE_256x256_FP8)) + ":" + o.name;
+    }
+    for (const auto& kv : h->named) {
+        const Range r = range(kv.second);
+        for (const Op& o : h->ops)
+            if (o.kind != OP_PRE && overlap(r, range(o.out)) && !o.write_f16) h->q_only.insert(kv.first);
+    }
 }
 
 void build_priors(yh_engine* h) {
@@ -648,7 +734,7 @@ hipError_t launch_conv_planned(const Tune& tu, const ConvParams& p, ConvTile til
     return hipSuccess;
 }
 
-int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
+int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile* tile_out = nullptr) {
     const Panel& pn = h->panels[o.panel];
     ConvParams p;
     memset(&p, 0, sizeof p);
@@ -675,7 +761,24 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out) {
     // timing-only ablation (tune.ablate): zero-record descriptors drop every load through them
     if (h->tune.ablate & 1) { p.x_bytes = 0; }
     if (h->tune.ablate & 2) { p.w_bytes = 0; }
-    const ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
+    ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
+    if (h->fp8_active) {
+        // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
+        p.y = o.write_f16 ? o.out.d : nullptr;
+        if (o.write_q) { p.y8 = o.out.q; p.y8_inv_scale = 1.0f / h->act_scale[o.out.sid]; }
+        if (o.fp8) {
+            // the loader's units stay 2 bytes: two E4M3 values (ConvParams: "fp8 form")
+            const long long zq = o.in.qzero - o.in.q;
+            if (zq < 0 || zq >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+            p.x = (const half_t*)o.in.q; p.w = (const half_t*)pn.w8; p.scale = pn.scale;
+            p.x_zero_off = (unsigned)zq; p.x_bytes = (unsigned)zq + 16u; p.w_bytes = (unsigned)((size_t)pn.coutPad * pn.Kpad);
+            if (h->tune.ablate & 1) { p.x_bytes = 0; }
+            if (h->tune.ablate & 2) { p.w_bytes = 0; }
+            p.C = pn.cin_store / 2; p.ldw = pn.Kpad / 2; p.ksteps = pn.Kpad / 128; p.x_img_stride = o.in.img_stride / 2;
+            tile = TILE_256x256_FP8;
+        }
+    }
+    if (tile_out) *tile_out = tile;
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
     const int splitk_min = h->tune.splitk_minsteps, t64_mode = h->tune.t64, t64_min = h->tune.t64_minsteps;
@@ -710,17 +813,20 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             break;
         case OP_CONV: {
             ConvParams p;
-            int rc = fill_conv_params(h, o, n, &p);
+            ConvTile tile;
+            int rc = fill_conv_params(h, o, n, &p, &tile);
             if (rc) return rc;
-            const Panel& pn = h->panels[o.panel];
-            e = launch_conv_planned(h->tune, p, pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, h->stream);
+            e = launch_conv_planned(h->tune, p, tile, h->panels[o.panel].coutPad, h->stream);
             break;
         }
         case OP_POOL:
             e = launch_maxpool3x3s2(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, h->stream);
             break;
         case OP_BILINEAR:
-            e = launch_bilinear(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream);
+            if (h->fp8_active)
+                e = launch_bilinear(o.in.d, o.write_f16 ? o.out.d : nullptr, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream,
+                                    o.write_q ? o.out.q : nullptr, o.write_q ? 1.0f / h->act_scale[o.out.sid] : 1.0f);
+            else e = launch_bilinear(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream);
             break;
         case OP_STEMPOOL: {
             const Panel& pn = h->panels[o.panel];
@@ -745,7 +851,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     // join before the mask kernel (event record / wait: valid under stream capture).
     bool tail_forked = false;
     for (size_t i = 0; i < h->ops.size(); ++i) {
-        if (with_tail && (int)i == h->tail_fork_op) {
+        if (with_tail && h->tune.tailfork && (int)i == h->tail_fork_op) {
             h->det.n = n;
             HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -772,6 +878,8 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
 int run(yh_engine* h, int with_tail) {
     if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no input set");
+    if (h->cfg.precision == YH_PRECISION_FP8 && !h->fp8_ready)
+        return h->fail(YH_ESTATE, "fp8 precision: the activation scales are not set - call yh_fp8_calibrate on representative frames first");
     HIPCHK(h, hipSetDevice(h->dev));
     const int n = h->cur_n;
     if (!h->cfg.use_graph) return enqueue_all(h, n, with_tail);
@@ -805,6 +913,12 @@ int alloc_panels(yh_engine* h) {
         p.w = (half_t*)q;
         if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * 4))) return rc;
         p.bias = (float*)q;
+        if (p.fp8) {
+            if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * p.Kpad))) return rc;
+            p.w8 = (uint8_t*)q;
+            if ((rc = dev_alloc(h, &q, (size_t)p.coutPad * 4))) return rc;
+            p.scale = (float*)q;
+        }
         if (p.tile == TILE_64x256_SMALLC) {
             const int nt = p.Kpad / 8, cpr = (p.k + 1) / 2;  // chunks per kernel row
             std::vector<int2> t(nt);
@@ -829,6 +943,17 @@ int check_blob(yh_engine* h, const uint8_t* b, size_t nbytes) {
         memcpy(rec, b + d.blob_w_off - 16, 16);
         if ((int)rec[0] != d.cout || (int)rec[1] != d.cin || (int)rec[2] != d.k || (int)rec[3] != d.k)
             return h->fail(YH_EWEIGHTS, "weight blob layer record mismatch");
+    }
+    return YH_OK;
+}
+
+// Per-channel output scales of the fp8 convolutions: s_x of the input tensor (calibrated) * s_w[ch].
+int refresh_fp8_scales(yh_engine* h) {
+    for (Panel& p : h->panels) {
+        if (!p.fp8 || p.sw.empty()) continue;
+        std::vector<float> sc(p.coutPad);
+        for (int r = 0; r < p.coutPad; ++r) sc[r] = h->act_scale[p.in_sid] * p.sw[r];
+        HIPCHK(h, hipMemcpy(p.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     }
     return YH_OK;
 }
@@ -859,8 +984,29 @@ int upload_panels(yh_engine* h, const uint8_t* blob) {
         }
         HIPCHK(h, hipMemcpy(p.w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(p.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+        if (p.fp8) {
+            // E4M3 weights, one scale per output channel: s_w = max |w| / 448 (1 for an all-zero row), codes =
+            // e4m3(w * (1 / s_w)) by the device's own conversion (the kernel yh_op_quantize_e4m3 tests against the oracle)
+            p.sw.assign(p.coutPad, 1.0f);
+            std::vector<float> inv(p.coutPad, 1.0f);
+            for (int r = 0; r < p.coutPad; ++r) {
+                float a = 0.0f;
+                for (int k = 0; k < p.Kpad; ++k) {
+                    const uint16_t b = w[(size_t)r * p.Kpad + k];
+                    _Float16 hv; memcpy(&hv, &b, 2);
+                    const float v = fabsf((float)hv);
+                    a = v > a ? v : a;
+                }
+                p.sw[r] = a > 0.0f ? a / 448.0f : 1.0f;
+                inv[r] = 1.0f / p.sw[r];
+            }
+            HIPCHK(h, hipMemcpy(p.scale, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));   // (borrowed as the 1 / s_w table for this one launch)
+            if (launch_quantize_rows_e4m3(p.w, p.w8, p.coutPad, p.Kpad, p.scale, h->stream) != hipSuccess) return h->fail(YH_EHIP, "weight quantisation launch failed");
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
     }
     h->weights_loaded = true;
+    if (h->fp8_ready) { const int rc = refresh_fp8_scales(h); if (rc) return rc; }
     return YH_OK;
 }
 
@@ -945,6 +1091,12 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     build_conv_table(h);
     int rc = build_graph_spec(h);
     if (rc) return bail(rc);
+    if (cfg->precision == YH_PRECISION_FP8) {
+        plan_fp8(h);
+        void* q = nullptr;
+        if ((rc = dev_alloc(h, &q, 256))) return bail(rc);
+        h->absmax_dev = (unsigned*)q;
+    }
     build_priors(h);
     if ((rc = alloc_tail(h))) return bail(rc);
     if ((rc = alloc_panels(h))) return bail(rc);
@@ -1006,8 +1158,66 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork;
     return YH_OK;
+}
+
+// ---- fp8 precision (configs[4]) ----------------------------------------------------------------------------
+int yh_fp8_layer_count(const yh_engine* h) { return h ? (int)h->fp8_ops.size() : YH_EINVAL; }
+
+int yh_fp8_layer_info(const yh_engine* h, int32_t i, const char** conv_name, float* act_scale) {
+    if (!h || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    const Op& o = h->ops[h->fp8_ops[i]];
+    if (conv_name) *conv_name = o.name.c_str();
+    if (act_scale) *act_scale = h->act_scale[o.in.sid];
+    return YH_OK;
+}
+
+int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale) {
+    if (!h || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    if (!(act_scale > 0.0f) || !(act_scale < 3.0e38f)) return h->fail(YH_EINVAL, "activation scale must be a positive finite number");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // the scales are baked into the captured launches
+    h->graphs.clear();
+    h->act_scale[h->ops[h->fp8_ops[i]].in.sid] = act_scale;
+    // every layer has a scale (default 1.0 until set): the handle counts as calibrated once the caller has set them
+    h->fp8_ready = true; h->fp8_active = true;
+    return h->weights_loaded ? refresh_fp8_scales(h) : YH_OK;
+}
+
+int yh_fp8_calibrate(yh_engine* h) {
+    if (!h) return YH_EINVAL;
+    if (h->cfg.precision != YH_PRECISION_FP8) return h->fail(YH_ESTATE, "the handle was not created with YH_PRECISION_FP8");
+    if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
+    if (h->cur_n < 1) return h->fail(YH_ESTATE, "no input set: calibration runs on the frames last set");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    // 1. the f16 forward of these frames (every tensor in f16, as a YH_PRECISION_F16 handle computes it)
+    h->fp8_active = false;
+    int rc = enqueue_all(h, h->cur_n, 0);
+    if (rc) return rc;
+    // 2. one scale per tensor that an fp8 convolution reads: max |x| / 448 (E4M3's largest finite value)
+    std::set<int> sids;
+    for (int oi : h->fp8_ops) sids.insert(h->ops[oi].in.sid);
+    if (sids.size() > 64) return h->fail(YH_EINVAL, "too many fp8 input tensors");
+    HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, 256, h->stream));
+    int k = 0;
+    for (int sid : sids)
+        if (launch_absmax_f16(h->alloc_base[sid], (long long)h->cur_n * h->alloc_img[sid], h->absmax_dev + k++, h->stream) != hipSuccess)
+            return h->fail(YH_EHIP, "absmax launch failed");
+    unsigned bits[64];
+    HIPCHK(h, hipMemcpyAsync(bits, h->absmax_dev, 256, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    k = 0;
+    for (int sid : sids) {
+        float a; memcpy(&a, &bits[k++], 4);
+        h->act_scale[sid] = a > 0.0f ? a / 448.0f : 1.0f;
+    }
+    h->fp8_ready = true; h->fp8_active = true;
+    return refresh_fp8_scales(h);
 }
 
 size_t yh_weights_nbytes(const yh_engine* h) { return h ? h->blob_bytes : 0; }
@@ -1473,7 +1683,10 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
     int rc = ensure_out_f32(h, per * n);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
-        hipError_t e = launch_f16_to_f32(b.d + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->stream);
+        hipError_t e;
+        if (h->fp8_active && h->q_only.count(name))
+            e = launch_dequant_e4m3_f32(b.q + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->act_scale[b.sid], h->stream);
+        else e = launch_f16_to_f32(b.d + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
     }
     HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1497,7 +1710,11 @@ int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, fl
     HIPCHK(h, hipSetDevice(h->dev));
     int rc = ensure_out_f32(h, per);
     if (rc) return rc;
-    if (launch_f16_to_f32(b.d + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->stream) != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
+    hipError_t ce;
+    if (h->fp8_active && h->q_only.count(name))   // fp8 precision: this tensor exists only as E4M3 codes
+        ce = launch_dequant_e4m3_f32(b.q + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->act_scale[b.sid], h->stream);
+    else ce = launch_f16_to_f32(b.d + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->stream);
+    if (ce != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
     HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return YH_OK;
@@ -1515,11 +1732,12 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         const Op& o = h->ops[i];
         if (o.kind != OP_CONV) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }
         ConvParams p;
-        const int rc = fill_conv_params(h, o, n, &p);
+        ConvTile tile;
+        const int rc = fill_conv_params(h, o, n, &p, &tile);
         if (rc) return rc;
         const Panel& pn = h->panels[o.panel];
         KLaunch k[2];
-        const int nk = plan_conv(h->tune, p, pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0), pn.coutPad, k);
+        const int nk = plan_conv(h->tune, p, tile, pn.coutPad, k);
         for (int j = 0; j < nk; ++j) { ProfEntry e{}; e.op = i; e.stage = -1; e.k = k[j]; e.is_conv = true; out->push_back(e); }
     }
     if (with_tail)

@@ -289,10 +289,7 @@ struct yh_tfl {
     std::vector<char> alias;    // tens[i] shares another tensor's buffer (RESHAPE): not freed twice
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
-    // the plan, captured once and replayed (tensor addresses never change), in segments of at most kGraphSegment
-    // kernels each (see run_plan)
-    std::vector<hipGraphExec_t> gexecs;
-    static const int kGraphSegment = 96;
+    hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
     int use_dot = 1, use_graph = 1;   // yh_tuning.tfl_dot / tfl_graph
     // classify scratch
     uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
@@ -508,13 +505,9 @@ int prepare(yh_tfl* h) {
     return YH_OK;
 }
 
-int plan_kernels(const Prepared& p) { return p.kind == P_CONCAT ? (int)p.cat.size() : 1; }
-
-int enqueue_plan(yh_tfl* h, size_t first = 0, size_t last = (size_t)-1) {
+int enqueue_plan(yh_tfl* h) {
     hipStream_t s = h->stream;
-    if (last > h->plan.size()) last = h->plan.size();
-    for (size_t pi = first; pi < last; ++pi) {
-        const Prepared& p = h->plan[pi];
+    for (const Prepared& p : h->plan) {
         switch (p.kind) {
             case P_CONV:
                 if (p.conv.wsum) {
@@ -541,41 +534,30 @@ int enqueue_plan(yh_tfl* h, size_t first = 0, size_t last = (size_t)-1) {
     return YH_OK;
 }
 
-// One invoke = a few graph launches (yh_tuning.tfl_graph, default 1; 0 = eager launches): 5 % faster per invoke on the
+// One invoke = one graph launch (yh_tuning.tfl_graph, default 1; 0 = eager launches): 5 % faster per invoke on the
 // 136-op model (1.09 vs 1.17 ms; the step is bound by kernel time, not by launches).
-// The plan is captured in SEGMENTS of at most kGraphSegment kernels. Round 1 captured the whole 137-kernel plan as one
-// graph; replayed under `rocprofv3 --kernel-trace` that graph crashed with SIGSEGV in a copy inside the profiler's
-// dispatch interception, called from hipGraphLaunch (profiles/r02_tflite_graph_crash_rocprofv3.log), while the same
-// graph replays cleanly without the profiler (600 invokes) and the YOLACT engine's 93-kernel graphs replay under it:
-// the profiler, not the plan, faults once a single graph launch carries more kernel dispatches than it copes with.
-// Keeping every graph launch under 100 kernels avoids that case at no measurable cost.
+// Round 1 shipped eager launches by default because `rocprofv3 --kernel-trace` crashed inside hipGraphLaunch on this
+// graph. Cause (round 2, profiles/r02_graph_replay_under_rocprofv3.md with the logs): not the plan. The HIP runtime
+// replays a SINGLE-BRANCH graph from AQL packets it pre-built at instantiation ("graph packet capture"), and rocprofv3's
+// queue interception faults on that path: the YOLACT engine's own step crashes the same way when captured without its
+// tail fork (yh_invoke), while every forked graph (yh_evaluate) is fine, and with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in
+// the environment both this graph and the engine's single-branch one replay 300 times under the profiler. Without
+// the profiler the graph replays cleanly (600 invokes). So graph replay is the default again; to profile a
+// single-branch graph, export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (tools/collect_profiles.sh does) or pass tfl_graph = 0.
 int run_plan(yh_tfl* h) {
     if (!h->use_graph) return enqueue_plan(h);
-    if (h->gexecs.empty()) {
-        size_t first = 0;
-        while (first < h->plan.size()) {
-            size_t last = first;
-            int kernels = 0;
-            while (last < h->plan.size() && (last == first || kernels + plan_kernels(h->plan[last]) <= yh_tfl::kGraphSegment)) kernels += plan_kernels(h->plan[last++]);
-            hipGraph_t g = nullptr;
-            TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-            const int rc = enqueue_plan(h, first, last);
-            const hipError_t e = hipStreamEndCapture(h->stream, &g);
-            hipGraphExec_t ge = nullptr;
-            hipError_t ei = hipSuccess;
-            if (!rc && e == hipSuccess && g) ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-            if (g) hipGraphDestroy(g);
-            if (rc || e != hipSuccess || ei != hipSuccess || !ge) {
-                for (hipGraphExec_t x : h->gexecs) hipGraphExecDestroy(x);
-                h->gexecs.clear();
-                if (rc) return rc;
-                return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e != hipSuccess ? e : ei));
-            }
-            h->gexecs.push_back(ge);
-            first = last;
-        }
+    if (!h->gexec) {
+        hipGraph_t g = nullptr;
+        TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_plan(h);
+        const hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { h->gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
     }
-    for (hipGraphExec_t ge : h->gexecs) TCHK(h, hipGraphLaunch(ge, h->stream));
+    TCHK(h, hipGraphLaunch(h->gexec, h->stream));
     return YH_OK;
 }
 
@@ -631,7 +613,7 @@ void yh_tfl_destroy(yh_tfl* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    for (hipGraphExec_t ge : h->gexecs) hipGraphExecDestroy(ge);
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
     for (size_t i = 0; i < h->tens.size(); ++i) if (h->tens[i] && !(i < h->alias.size() && h->alias[i])) hipFree(h->tens[i]);
     for (void* p : h->extra) hipFree(p);
     void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };

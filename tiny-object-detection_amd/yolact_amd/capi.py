@@ -22,11 +22,11 @@ PRECISION_F16, PRECISION_FP8 = 0, 1
 # yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
 TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
                  "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
-                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph")
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork")
 
 
 class Tuning(C.Structure):
-    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 7)]
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 6)]
 
     @classmethod
     def of(cls, **kw):
@@ -77,6 +77,10 @@ SYMBOLS = [
     ("yh_weights_generate", _i, [_vp, C.c_uint64, _vp, _sz]),
     ("yh_load_weights_host", _i, [_vp, _vp, _sz]),
     ("yh_load_weights_device", _i, [_vp, _vp, _sz]),
+    ("yh_fp8_calibrate", _i, [_vp]),
+    ("yh_fp8_layer_count", _i, [_vp]),
+    ("yh_fp8_layer_info", _i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_f)]),
+    ("yh_fp8_set_layer_scale", _i, [_vp, _i, _f]),
     ("yh_group_broadcast_weights", _i, [C.POINTER(_vp), _i, _i]),
     ("yh_rccl_unique_id", _i, [_vp]),
     ("yh_rank_broadcast_weights", _i, [_vp, _vp, _i, _i, _i]),
@@ -260,6 +264,23 @@ class Engine:
 
     def load_weights_device(self, dev_ptr, nbytes):
         self._chk(self.L.yh_load_weights_device(self.h, C.c_void_p(dev_ptr), nbytes))
+
+    # ---- fp8 precision (configs[4])
+    def fp8_calibrate(self):
+        """Sets every fp8 input tensor's scale from the f16 forward of the frames last set."""
+        self._chk(self.L.yh_fp8_calibrate(self.h))
+
+    def fp8_layers(self):
+        """[(conv name, activation scale)] of the convolutions that read E4M3 operands, in execution order."""
+        out = []
+        for i in range(self.L.yh_fp8_layer_count(self.h)):
+            name, sc = C.c_char_p(), C.c_float()
+            self._chk(self.L.yh_fp8_layer_info(self.h, i, C.byref(name), C.byref(sc)))
+            out.append((name.value.decode(), sc.value))
+        return out
+
+    def fp8_set_layer_scale(self, i, scale):
+        self._chk(self.L.yh_fp8_set_layer_scale(self.h, i, C.c_float(scale)))
 
     def rank_broadcast_weights(self, id_bytes, rank, nranks, root=0):
         """One process per GPU: RCCL broadcast of the root rank's weights (id_bytes from rccl_unique_id on one rank)."""
