@@ -299,6 +299,33 @@ int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes);   /
  * invoke each, output 4 dequantised (:177) and post-processed (:90-131), all on device. */
 int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame_host, int32_t width, int32_t height, int32_t compat_mode);
 
+/* ---- scene back-end: append_scene's two compute dispatches (src/scene.rs:147-331) --------------
+ * shaders/pt_cloud.comp (depth + class image -> bird's-eye height map with sigmoid bumps, ball centroids) and
+ * shaders/pt_cloud_weights.comp (world positions, 8-neighbour edge lengths) as HIP kernels, one lane per pixel in
+ * 8x8 workgroups ([80,60,1] at 640x480: scene.rs:245,:256). The shaders as written race and use undefined GLSL;
+ * what is computed is the deterministic reading of DESIGN.md §Scene (stage-by-stage completion, exact ball means).
+ * compat_mode: YH_COMPAT_STRICT keeps pack()'s `&` (pt_cloud_weights.comp:32: every neighbour position decodes to
+ * world(0,0)); YH_COMPAT_SANE measures the distance to the actual neighbour. */
+typedef struct yh_scene yh_scene;
+int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** out);   /* scene.rs:150-155: the storage images */
+void yh_scene_destroy(yh_scene* h);
+const char* yh_scene_last_error(const yh_scene* h);
+/* One frame: depth u16 [h][w] (the R16_UINT texture, scene.rs:197) and the class image [h][w][2] = (class, id) (the
+ * R8G8_UINT texture, scene.rs:198), both in host memory. Asynchronous on the handle's stream. */
+int yh_scene_append(yh_scene* h, const uint16_t* depth_host, const uint8_t* class_id_host, int32_t compat_mode);
+/* The class image taken straight from a classified frame as yh_classify_frame_u32 leaves it (packed u32 [h][w];
+ * frame_on_device = 1: a device pointer, e.g. yh_classify_device_frame - no host round trip of the class image).
+ * STRICT reads it as the reference does - the low 16 bits (src/scene.rs:93), class = bits 7-0, id = bits 15-8, which
+ * classify leaves zero - SANE reads class = bits 31-24, id = bits 23-16. */
+int yh_scene_append_classified(yh_scene* h, const uint16_t* depth_host, const uint32_t* frame, int32_t frame_on_device, int32_t compat_mode);
+/* scene.rs:284-330: height map u32 [h][w], world / connections0 / connections1 f32 [h][w][4], balls f32 [100][4]
+ * = (mean x, mean y, pixel count, 0). Any pointer may be NULL. Waits for the frame. */
+int yh_scene_read(yh_scene* h, uint32_t* map, float* world, float* conn0, float* conn1, float* balls);
+/* Measurement hook: mean device milliseconds per frame over `reps` re-runs of the last appended frame. */
+int yh_scene_time(yh_scene* h, int32_t reps, float* ms_per_frame);
+/* Device copy of the frame the last yh_classify_frame_u32 produced (valid until the next classify on this handle). */
+const uint32_t* yh_classify_device_frame(const yh_engine* h);
+
 /* Test hook: copies the named intermediate tensor of the last forward (layer names of DESIGN.md:
  * "stem", "pool", "c2".."c5", "lat3".."lat5", "p3".."p7", "proto0".."proto3", "proto_up", "head_t0"..) to
  * host memory as f32 NHWC; dims receives {n,h,w,c}. Returns YH_EINVAL for unknown names. "stem" is

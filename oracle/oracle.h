@@ -106,6 +106,12 @@ float orc_e4m3_to_f32(uint8_t b);
 uint8_t orc_e4m3_from_f32(float x);              /* round to nearest even, saturating at +-448, NaN -> 0x7F */
 void orc_quantize_e4m3(const float* x, long long n, float inv_scale, uint8_t* y);
 
+/* ---- scene back-end (orc_scene.c): SURVEY.md §8f-4, shaders/pt_cloud.comp + pt_cloud_weights.comp. PARITY UNPINNED
+ * (the shaders race and use undefined GLSL; the file header lists what is frozen instead). */
+float orc_spec_logf(float x);
+void orc_scene(const uint16_t* depth, const uint8_t* cls_id, int W, int H, int mode,
+               uint32_t* map, float* world, float* conn0, float* conn1, float* balls);
+
 #ifdef __cplusplus
 }
 #endif

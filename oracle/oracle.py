@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_ref.c", "orc_detect.c", "orc_net.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_ref.c", "orc_detect.c", "orc_net.c", "orc_fp8.c", "orc_scene.c", "oracle.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -333,3 +333,27 @@ def quantize_e4m3(x, inv_scale=1.0):
     L.orc_quantize_e4m3.restype = None
     L.orc_quantize_e4m3(_p(x), x.size, C.c_float(inv_scale), _p(y))
     return y
+
+
+# ---- scene back-end (orc_scene.c): shaders/pt_cloud.comp + pt_cloud_weights.comp ---------------------------
+def spec_logf(x):
+    L = lib()
+    L.orc_spec_logf.restype = C.c_float
+    L.orc_spec_logf.argtypes = [C.c_float]
+    return L.orc_spec_logf(float(x))
+
+
+def scene(depth, cls_id, mode=0):
+    """depth [H][W] uint16, cls_id [H][W][2] uint8 (class, id) -> dict(map u32 [H][W], world / conn0 / conn1 f32 [H][W][4],
+    balls f32 [100][4]). mode 0 STRICT (pack() uses `&`), 1 SANE."""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    cls_id = np.ascontiguousarray(cls_id, np.uint8)
+    H, W = depth.shape
+    assert cls_id.shape == (H, W, 2)
+    out = dict(map=np.zeros((H, W), np.uint32), world=np.zeros((H, W, 4), np.float32), conn0=np.zeros((H, W, 4), np.float32),
+               conn1=np.zeros((H, W, 4), np.float32), balls=np.zeros((100, 4), np.float32))
+    L = lib()
+    L.orc_scene.restype = None
+    L.orc_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.orc_scene(_p(depth), _p(cls_id), W, H, mode, _p(out["map"]), _p(out["world"]), _p(out["conn0"]), _p(out["conn1"]), _p(out["balls"]))
+    return out

@@ -54,8 +54,12 @@ def test_fp8_needs_scales_and_lists_its_layers(fp8_setup):
 def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
     """Tolerance, stated: both sides quantise the same f16-rounded tensors with the same scales, but their inputs differ
     by f16 summation-order noise, and an activation that sits near an E4M3 rounding boundary then takes the neighbouring
-    code on one side (a 6-12 % step of that one operand). Heads: max |err| <= 8 % of the tensor's absmax, rms err <= 2 %
-    of its rms (the f16 path's bounds are 3 % / 0.5 %)."""
+    code on one side (a 6-12 % step of that one operand): a 0.1 % input difference flips 1-2 % of the codes of a tensor, i.e.
+    ~1 % rms per quantised layer, and ~13 chained quantised layers compound it. Heads: max |err| <= 12 % of the tensor's
+    absmax, rms err <= 6 % of its rms (measured 4.1 % on loc; the f16 path's bounds are 3 % / 0.5 %; fp8 vs f16 itself
+    differs by 4-10 % rms); the measured figures are printed (pytest -s). Because that end-to-end bound is loose by
+    nature, test_fp8_single_layers_are_tight checks every kind of fp8 layer on IDENTICAL quantised inputs, where only the
+    summation order remains."""
     eng, blob, img, S = fp8_setup
     eng.set_input(img)
     eng.fp8_calibrate()
@@ -64,14 +68,31 @@ def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
     net = oracle.Net(50, S, 81, blob=blob)
     net.set_fp8(_expand(eng.fp8_layers()))
     want = net.forward(img, f16=True)
-    for name, tol in (("l3b0_a", 2e-2), ("l3b0_b", 4e-2), ("c4", 4e-2), ("c5", 5e-2), ("lat5", 5e-2), ("p5", 6e-2), ("p3", 6e-2), ("p7", 8e-2), ("proto2", 8e-2),
-                      ("proto3", 8e-2), ("head_t0", 8e-2), ("head_t2", 8e-2), ("head_t4", 8e-2)):
+    sc = dict(eng.fp8_layers())
+    consumer = {"l3b0_a": "l3b0_b", "p5": "head_t", "p3": "head_t", "p7": "head_t", "proto1": "proto2"}
+    # Intermediate tensors. A tensor that only fp8 convolutions read exists in the engine only as E4M3 codes (what
+    # yh_debug_read_tensor returns is their decoded value), while the oracle stores it in f16 and quantises where it
+    # is consumed: for those the bound includes E4M3's half step (2^-4 relative = 6.25 %, of at most the tensor's absmax).
+    for name, tol, q_only in (("l3b0_a", 2e-2, True), ("l3b0_b", 4e-2, False), ("c4", 4e-2, False), ("c5", 5e-2, False), ("lat5", 5e-2, False),
+                              ("p5", 6e-2, True), ("p3", 6e-2, True), ("p7", 8e-2, True), ("proto1", 8e-2, True), ("proto2", 8e-2, False),
+                              ("proto3", 0.12, False), ("head_t0", 8e-2, False), ("head_t2", 8e-2, False), ("head_t4", 8e-2, False)):
         a, b = eng.tensor(name), net.get(name)
         assert a.shape == b.shape, name
-        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+        bound = (tol + (0.0625 if q_only else 0.0)) * max(1.0, np.abs(b).max())
+        print(f"fp8 engine vs fp8 oracle {name}: max |err| {np.abs(a - b).max():.4f} = {100 * np.abs(a - b).max() / max(1.0, np.abs(b).max()):.2f} % of absmax (bound {100 * bound / max(1.0, np.abs(b).max()):.1f} %)")
+        assert np.abs(a - b).max() <= bound, (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+        if q_only:   # and every decoded value is an E4M3 value times the tensor's scale
+            s_t = sc[consumer[name]]
+            table = np.sort(oracle.e4m3_decode_table()[np.isfinite(oracle.e4m3_decode_table())].astype(np.float64))
+            q = a.astype(np.float64).ravel() / s_t
+            near = table[np.clip(np.searchsorted(table, q), 1, len(table) - 1)]
+            near2 = table[np.clip(np.searchsorted(table, q), 1, len(table) - 1) - 1]
+            err = np.minimum(np.abs(q - near), np.abs(q - near2))
+            assert (err <= 1e-5 * np.maximum(1.0, np.abs(q))).all(), name
     for name, a, b in zip(("loc", "conf", "mask", "proto"), got, want):
-        assert np.abs(a - b).max() <= 0.08 * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
-        assert np.sqrt(((a - b) ** 2).mean()) <= 2e-2 * np.sqrt((b ** 2).mean()) + 1e-4, (name, float(np.sqrt(((a - b) ** 2).mean())), float(np.sqrt((b ** 2).mean())))
+        mx, rms = float(np.abs(a - b).max() / max(1.0, np.abs(b).max())), float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+        print(f"fp8 engine vs fp8 oracle {name}: max |err| {100 * mx:.2f} % of absmax, rms err {100 * rms:.3f} % of rms")
+        assert mx <= 0.12 and rms <= 6e-2, (name, mx, rms)
     # the tail is precision-independent: bit-exact on the engine's own heads
     pri = net.priors()
     for f in range(2):
@@ -83,6 +104,45 @@ def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
     eng.evaluate()
     for i in range(4):
         assert np.array_equal(eng.output(i), got[i])
+
+
+def test_fp8_single_layers_are_tight(fp8_setup, oracle):
+    """One fp8 convolution at a time on identical inputs: the engine's own E4M3 input tensor (decoded exactly), the blob's
+    weights quantised per output channel as DESIGN.md §Precision states, f32 convolution of the decoded operands by the
+    oracle, y = relu(fma(acc, s_x * s_w, bias)) rounded to f16 - against the engine's output of that layer. Only the f32
+    summation order differs: <= 2 f16 ulp. Covers a backbone 3x3 (l3b0_b), a protonet conv (proto1) and the multi-level
+    shared head trunk on all five pyramid levels (a tap that left its level would be an O(1) error)."""
+    import bench
+    eng, blob, img, S = fp8_setup
+    eng.set_input(img); eng.fp8_calibrate(); eng.evaluate()
+    sc = dict(eng.fp8_layers())
+    convs = bench.parse_blob(blob)
+    table = oracle.e4m3_decode_table()
+
+    def fq_weights(w):   # [cout][k][k][cin] -> decoded E4M3 values and the per-channel scale
+        aw = np.abs(w).reshape(w.shape[0], -1).max(1).astype(np.float32)
+        sw = np.where(aw > 0, aw / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+        inv = (np.float32(1.0) / sw).astype(np.float32)
+        q = np.stack([table[oracle.quantize_e4m3(w[o], float(inv[o]))] for o in range(w.shape[0])])
+        return q.astype(np.float32), sw
+
+    def check(layer, x_name, y_name, conv_index, stride=1):
+        s_x = np.float32(sc[layer])
+        xq = table[oracle.quantize_e4m3((eng.tensor(x_name).astype(np.float32) / s_x).astype(np.float32), 1.0)]   # the codes' exact values
+        assert np.abs(xq * s_x - eng.tensor(x_name)).max() <= 1e-6 * np.abs(xq * s_x).max()
+        w, b = convs[conv_index]
+        wq, sw = fq_weights(w)
+        acc = oracle.conv2d(xq, wq, np.zeros(w.shape[0], np.float32), stride, 1, None, 0, f16=False)
+        want = np.maximum(acc * (s_x * sw) + b, 0).astype(np.float16).astype(np.float32)
+        got = eng.tensor(y_name)
+        ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
+        bad = np.abs(got - want) > 2 * ulp + 1e-6
+        assert got.shape == want.shape and bad.mean() == 0, (layer, y_name, float(np.abs(got - want).max()), float(bad.mean()))
+    check("l3b0_b", "l3b0_a", "l3b0_b", 25, stride=2)
+    for l in range(5):
+        check("head_t", f"p{l + 3}", f"head_t{l}", 66)
+    # proto1's output exists only as E4M3 in the engine: compare proto2 (f16 output) from proto1's codes instead
+    check("proto2", "proto1", "proto2", 63)
 
 
 def test_fp8_vs_f16_gap_is_reported_with_its_own_bound(fp8_setup, built):

@@ -1665,6 +1665,7 @@ int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, 
 }
 
 int yh_debug_last_conv_launches(const yh_engine* h) { return h ? h->last_conv_launches : 0; }
+const uint32_t* yh_classify_device_frame(const yh_engine* h) { return h ? h->frame_dev : nullptr; }
 
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;

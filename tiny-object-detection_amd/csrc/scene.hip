@@ -1,0 +1,283 @@
+// scene.hip — the reference's scene back-end on the GPU: height map with sigmoid "bumps" and
+// ball centroids (/root/reference/shaders/pt_cloud.comp), world positions and 8-neighbour edge lengths
+// (/root/reference/shaders/pt_cloud_weights.comp), driven as /root/reference/src/scene.rs:147-331 (append_scene)
+// drives its two Vulkan dispatches of [80,60,1] x 8x8 over a 640x480 frame (scene.rs:245,:256).
+//
+// What is computed is the deterministic reading frozen in DESIGN.md §Scene and restated in oracle/orc_scene.c (the
+// shaders as written race - store_ball, barrier() used as a grid barrier - and call pow() where GLSL leaves it
+// undefined): every stage completes over the whole frame before the next starts (one launch per stage); texel (x, y)
+// is read for pixel (x, y); squares are products; a bump whose sigmoid base is not positive adds nothing; ball
+// centroids are exact integer means. Integer outputs and every float are bit-identical to the oracle: one IEEE
+// operation per operator (-ffp-contract=off, explicit _rn intrinsics for sqrt and division).
+// HBM / atomic-bound byte work: one lane per pixel, 8x8 workgroups as the dispatch the reference uses; the height map
+// is built with atomicMax on 32-bit words as the shader's imageAtomicMax does.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <string>
+
+#include "yh_internal.h"
+
+using namespace yh;
+
+namespace {
+
+#define SC_MAX_DEPTH 4000.0f
+#define SC_TAN_HALF_YFOV 0.55430907f
+#define SC_TAN_HALF_XFOV 0.9489646f
+#define SC_BOT_AVOID 100.0f
+#define SC_BOT_NORM 20
+#define SC_TERRAIN_NORM 10
+#define SC_BUMP_ERR 0.1f
+
+struct SceneParams {
+    const uint16_t* depth;        // [H][W]
+    const uint8_t* cls_id;        // [H][W][2] (class, id), or nullptr when `frame` is given
+    const uint32_t* frame;        // [H][W] packed pixels as classify leaves them
+    int frame_mode;               // with `frame`: 0 = low 16 bits as src/scene.rs:93 reads them, 1 = class bits 31-24, id bits 23-16
+    int W, H, mode;
+    uint32_t* map;                // [H][W]
+    float4 *world, *conn0, *conn1;
+    long long* ball_acc;          // [3][100]: sum x, sum y, count
+    float4* balls;                // [100]
+};
+
+__device__ __forceinline__ void bump(const SceneParams& p, int px, int py, float val, int L) {
+    const float C1 = __fsub_rn(__fdiv_rn(val, SC_BUMP_ERR), 1.0f), C2 = __fdiv_rn(2.0f, (float)L);
+    if (!(C1 > 0.0f)) return;
+    const float logC1 = spec_logf(C1);   // pow(C_1, e) = exp(e * log(C_1)): the logarithm does not depend on the tap
+    for (int lx = 0; lx < 2 * L; ++lx)
+        for (int ly = 0; ly < 2 * L; ++ly) {
+            const int x = px - L + lx, y = py - L + ly;
+            if (x > 0 && y > 0 && x < p.W - 1 && y < p.H - 1) {
+                const int dx = px - x, dy = py - y;
+                const float prox = __fsqrt_rn((float)(dx * dx + dy * dy));
+                const float e = __fsub_rn(__fmul_rn(C2, prox), 1.0f);
+                const float y_add = __fdiv_rn(val, __fadd_rn(1.0f, spec_expf(__fmul_rn(e, logC1))));
+                const uint32_t v = y_add >= 1.0f ? (uint32_t)y_add : 0u;
+                if (v) atomicMax(p.map + (size_t)y * p.W + x, v);
+            }
+        }
+}
+
+// pt_cloud.comp main (:84-123)
+__global__ __launch_bounds__(64) void scene_cloud(const SceneParams p) {
+    const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    if (x >= p.W || y >= p.H) return;
+    const size_t i = (size_t)y * p.W + x;
+    const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
+    const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
+    const float cy = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(ty, ty))));
+    const float cx = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(tx, tx))));
+    const float d = __fmul_rn(__fmul_rn((float)p.depth[i], cy), cx);
+    const int dic = (int)__fdiv_rn(__fmul_rn((float)p.H, d), SC_MAX_DEPTH);
+    int cls, id;
+    if (p.cls_id) { cls = p.cls_id[2 * i]; id = p.cls_id[2 * i + 1]; }
+    else {
+        const uint32_t px = p.frame[i];
+        if (p.frame_mode == 0) { cls = (int)(px & 0xFFu); id = (int)((px >> 8) & 0xFFu); }   // `as u16` then R8G8 (scene.rs:93, :198)
+        else { cls = (int)(px >> 24); id = (int)((px >> 16) & 0xFFu); }
+    }
+    int action = cls;
+    if (action > 1) action = action - 1;
+    const int nx = x, ny = p.H - dic;
+    if (action == 0) bump(p, nx, ny, (float)y, SC_TERRAIN_NORM);
+    else if (action == 2) {
+        if (id < 100) {
+            atomicAdd((unsigned long long*)p.ball_acc + id, (unsigned long long)(long long)nx);
+            atomicAdd((unsigned long long*)p.ball_acc + 100 + id, (unsigned long long)(long long)ny);
+            atomicAdd((unsigned long long*)p.ball_acc + 200 + id, 1ull);
+        }
+    } else bump(p, nx, ny, SC_BOT_AVOID, SC_BOT_NORM);
+}
+
+__global__ void scene_balls(const SceneParams p) {
+    const int k = threadIdx.x;
+    if (k >= 100) return;
+    const long long sx = p.ball_acc[k], sy = p.ball_acc[100 + k], n = p.ball_acc[200 + k];
+    p.balls[k] = make_float4(n ? (float)((double)sx / (double)n) : 0.0f, n ? (float)((double)sy / (double)n) : 0.0f, (float)n, 0.0f);
+}
+
+// pt_cloud_weights.comp stage 1 (:57-87)
+__global__ __launch_bounds__(64) void scene_world(const SceneParams p) {
+    const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    if (x >= p.W || y >= p.H) return;
+    const size_t i = (size_t)y * p.W + x;
+    p.world[i] = make_float4((float)x, (float)p.map[i], (float)y, 0.0f);
+}
+
+// stage 2 (:91-111): r (x, y+1), g (x-1, y+1), b (x-1, y), a (x-1, y-1)
+__global__ __launch_bounds__(64) void scene_conn1(const SceneParams p) {
+    const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    if (x >= p.W || y >= p.H) return;
+    const size_t i = (size_t)y * p.W + x;
+    const float4 me = p.world[i];
+    const int ox[4] = { 0, -1, -1, -1 }, oy[4] = { 1, 1, 0, -1 };
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qx = x + ox[k], qy = y + oy[k];
+        v[k] = -1.0f;
+        if (qx >= 0 && qx < p.W && qy >= 0 && qy < p.H) {
+            // STRICT: pack(x, y) = float((x << 16) & y) is 0 for every pixel (pt_cloud_weights.comp:32), so unpack()
+            // returns world(0, 0) whoever the neighbour is; SANE: the neighbour's own position
+            const float4 o = p.world[p.mode == 0 ? 0 : (size_t)qy * p.W + qx];
+            const float dx = __fsub_rn(me.x, o.x), dy = __fsub_rn(me.y, o.y), dz = __fsub_rn(me.z, o.z);
+            v[k] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        }
+    }
+    p.conn1[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// stage 3 (:115-123): r (x, y-1), g (x+1, y-1), b (x+1, y), a (x+1, y+1)
+__global__ __launch_bounds__(64) void scene_conn0(const SceneParams p) {
+    const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    if (x >= p.W || y >= p.H) return;
+    const size_t i = (size_t)y * p.W + x;
+    const int ox[4] = { 0, 1, 1, 1 }, oy[4] = { -1, -1, 0, 1 };
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qx = x + ox[k], qy = y + oy[k];
+        v[k] = -1.0f;
+        if (qx >= 0 && qx < p.W && qy >= 0 && qy < p.H) {
+            const float4 o = p.conn1[(size_t)qy * p.W + qx];
+            v[k] = k == 0 ? o.x : (k == 1 ? o.y : (k == 2 ? o.z : o.w));
+        }
+    }
+    p.conn0[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+thread_local std::string g_scene_create_error;
+
+}  // namespace
+
+struct yh_scene {
+    int dev = 0, W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint16_t* depth = nullptr;
+    uint8_t* cls_id = nullptr;
+    uint32_t* frame = nullptr;
+    uint32_t* map = nullptr;
+    float4 *world = nullptr, *conn0 = nullptr, *conn1 = nullptr, *balls = nullptr;
+    long long* ball_acc = nullptr;
+    bool ran = false;
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+#define SCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (h)->fail(YH_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+int run_scene(yh_scene* h, const uint16_t* depth_dev, const uint8_t* cls_dev, const uint32_t* frame_dev, int frame_mode, int mode) {
+    SceneParams p;
+    p.depth = depth_dev; p.cls_id = cls_dev; p.frame = frame_dev; p.frame_mode = frame_mode;
+    p.W = h->W; p.H = h->H; p.mode = mode;
+    p.map = h->map; p.world = h->world; p.conn0 = h->conn0; p.conn1 = h->conn1; p.ball_acc = h->ball_acc; p.balls = h->balls;
+    const size_t npx = (size_t)h->W * h->H;
+    SCHK(h, hipMemsetAsync(h->map, 0, npx * 4, h->stream));
+    SCHK(h, hipMemsetAsync(h->ball_acc, 0, 300 * sizeof(long long), h->stream));
+    const dim3 grid((unsigned)((h->W + 7) / 8), (unsigned)((h->H + 7) / 8)), block(8, 8);   // [80,60,1] x 8x8 at 640x480 (scene.rs:245,:256)
+    hipLaunchKernelGGL(scene_cloud, grid, block, 0, h->stream, p);
+    hipLaunchKernelGGL(scene_balls, dim3(1), dim3(128), 0, h->stream, p);
+    hipLaunchKernelGGL(scene_world, grid, block, 0, h->stream, p);
+    hipLaunchKernelGGL(scene_conn1, grid, block, 0, h->stream, p);
+    hipLaunchKernelGGL(scene_conn0, grid, block, 0, h->stream, p);
+    SCHK(h, hipGetLastError());
+    h->ran = true;
+    return YH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* yh_scene_last_error(const yh_scene* h) { return h ? h->err.c_str() : g_scene_create_error.c_str(); }
+
+int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** out) {
+    if (!out) { g_scene_create_error = "null argument"; return YH_EINVAL; }
+    *out = nullptr;
+    if (width < 3 || height < 3 || width > 8192 || height > 8192) { g_scene_create_error = "frame size out of range"; return YH_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_scene_create_error = "no such HIP device (no CPU fallback)"; return YH_EHIP; }
+    yh_scene* h = new yh_scene();
+    h->dev = device; h->W = width; h->H = height;
+    const size_t npx = (size_t)width * height;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->depth, npx * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cls_id, npx * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->frame, npx * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->map, npx * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->world, npx * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->conn0, npx * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->conn1, npx * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->balls, 100 * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ball_acc, 300 * sizeof(long long));
+    if (e != hipSuccess) { g_scene_create_error = std::string("scene setup: ") + hipGetErrorString(e); yh_scene_destroy(h); return YH_EHIP; }
+    *out = h;
+    return YH_OK;
+}
+
+void yh_scene_destroy(yh_scene* h) {
+    if (!h) return;
+    hipSetDevice(h->dev);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* bufs[] = { h->depth, h->cls_id, h->frame, h->map, h->world, h->conn0, h->conn1, h->balls, h->ball_acc };
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int yh_scene_append(yh_scene* h, const uint16_t* depth_host, const uint8_t* class_id_host, int32_t mode) {
+    if (!h || !depth_host || !class_id_host) return YH_EINVAL;
+    if (mode != YH_COMPAT_STRICT && mode != YH_COMPAT_SANE) return h->fail(YH_EINVAL, "bad compat mode");
+    SCHK(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)h->W * h->H;
+    SCHK(h, hipMemcpyAsync(h->depth, depth_host, npx * 2, hipMemcpyHostToDevice, h->stream));
+    SCHK(h, hipMemcpyAsync(h->cls_id, class_id_host, npx * 2, hipMemcpyHostToDevice, h->stream));
+    return run_scene(h, h->depth, h->cls_id, nullptr, 0, mode);
+}
+
+int yh_scene_append_classified(yh_scene* h, const uint16_t* depth_host, const uint32_t* frame, int32_t frame_on_device, int32_t mode) {
+    if (!h || !depth_host || !frame) return YH_EINVAL;
+    if (mode != YH_COMPAT_STRICT && mode != YH_COMPAT_SANE) return h->fail(YH_EINVAL, "bad compat mode");
+    SCHK(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)h->W * h->H;
+    SCHK(h, hipMemcpyAsync(h->depth, depth_host, npx * 2, hipMemcpyHostToDevice, h->stream));
+    const uint32_t* fdev = frame;
+    if (!frame_on_device) { SCHK(h, hipMemcpyAsync(h->frame, frame, npx * 4, hipMemcpyHostToDevice, h->stream)); fdev = h->frame; }
+    return run_scene(h, h->depth, nullptr, fdev, mode == YH_COMPAT_STRICT ? 0 : 1, mode);
+}
+
+int yh_scene_read(yh_scene* h, uint32_t* map, float* world, float* conn0, float* conn1, float* balls) {
+    if (!h) return YH_EINVAL;
+    if (!h->ran) return h->fail(YH_ESTATE, "no frame has been appended");
+    SCHK(h, hipSetDevice(h->dev));
+    const size_t npx = (size_t)h->W * h->H;
+    if (map) SCHK(h, hipMemcpyAsync(map, h->map, npx * 4, hipMemcpyDeviceToHost, h->stream));
+    if (world) SCHK(h, hipMemcpyAsync(world, h->world, npx * 16, hipMemcpyDeviceToHost, h->stream));
+    if (conn0) SCHK(h, hipMemcpyAsync(conn0, h->conn0, npx * 16, hipMemcpyDeviceToHost, h->stream));
+    if (conn1) SCHK(h, hipMemcpyAsync(conn1, h->conn1, npx * 16, hipMemcpyDeviceToHost, h->stream));
+    if (balls) SCHK(h, hipMemcpyAsync(balls, h->balls, 100 * 16, hipMemcpyDeviceToHost, h->stream));
+    SCHK(h, hipStreamSynchronize(h->stream));
+    return YH_OK;
+}
+
+int yh_scene_time(yh_scene* h, int32_t reps, float* ms_per_frame) {
+    if (!h || reps < 1 || !ms_per_frame) return YH_EINVAL;
+    if (!h->ran) return h->fail(YH_ESTATE, "no frame has been appended");
+    SCHK(h, hipSetDevice(h->dev));
+    hipEvent_t a, b;
+    SCHK(h, hipEventCreate(&a)); SCHK(h, hipEventCreate(&b));
+    SCHK(h, hipEventRecord(a, h->stream));
+    for (int r = 0; r < reps; ++r) { const int rc = run_scene(h, h->depth, h->cls_id, nullptr, 0, YH_COMPAT_SANE); if (rc) return rc; }
+    SCHK(h, hipEventRecord(b, h->stream));
+    SCHK(h, hipEventSynchronize(b));
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    *ms_per_frame = ms / reps;
+    return YH_OK;
+}
+
+}  // extern "C"

@@ -171,6 +171,21 @@ __device__ __forceinline__ float spec_expf(float x) {
     int bits = __float_as_int(y) + ((int)n << 23);
     return __int_as_float(bits);
 }
+// natural logarithm of a positive normal float (scene back-end's sigmoid bump: pow(a, e) = exp(e * log(a))).
+// Identical source in oracle/orc_scene.c (it is the spec).
+__device__ __forceinline__ float spec_logf(float x) {
+    unsigned b = __float_as_uint(x);
+    int ex = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = __fmul_rn(m, 0.5f); ex += 1; }
+    const float f = __fsub_rn(m, 1.0f), s = __fdiv_rn(f, __fadd_rn(2.0f, f)), z = __fmul_rn(s, s);
+    float p = __fmaf_rn(z, 0.11111111f, 0.14285715f);
+    p = __fmaf_rn(p, z, 0.2f);
+    p = __fmaf_rn(p, z, 0.33333334f);
+    const float s2 = __fadd_rn(s, s);
+    const float r = __fmaf_rn(__fmul_rn(s2, z), p, s2);
+    return __fmaf_rn((float)ex, 0.69314718f, r);
+}
 __device__ __forceinline__ float spec_tanhf(float x) {
     float a = fabsf(x);
     float e = spec_expf(__fmul_rn(-2.0f, a));

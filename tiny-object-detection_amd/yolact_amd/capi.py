@@ -119,6 +119,14 @@ SYMBOLS = [
     ("yh_tfl_tensor_count", _i, [_vp]),
     ("yh_tfl_tensor_read", _i, [_vp, _i, _vp, _sz]),
     ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
+    ("yh_scene_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
+    ("yh_scene_destroy", None, [_vp]),
+    ("yh_scene_last_error", C.c_char_p, [_vp]),
+    ("yh_scene_append", _i, [_vp, _vp, _vp, _i]),
+    ("yh_scene_append_classified", _i, [_vp, _vp, _vp, _i, _i]),
+    ("yh_scene_read", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    ("yh_scene_time", _i, [_vp, _i, C.POINTER(_f)]),
+    ("yh_classify_device_frame", _vp, [_vp]),
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_read_tensor_frame", _i, [_vp, C.c_char_p, _i, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
@@ -346,6 +354,10 @@ class Engine:
         return self.L.yh_flops_per_frame(self.h)
 
     # ---- reference-compat path
+    def classify_device_frame(self):
+        """Device pointer of the frame the last classify_frame produced (for Scene.append_classified)."""
+        return self.L.yh_classify_device_frame(self.h)
+
     def classify_frame(self, frame_u32, width, height, mode=COMPAT_STRICT):
         """In place on a C-contiguous uint32 array of width*height packed pixels."""
         assert frame_u32.dtype == np.uint32 and frame_u32.flags.c_contiguous and frame_u32.size == width * height
@@ -492,6 +504,58 @@ class Engine:
         lb, cb, mb, pb = _f16_bits(loc), _f16_bits(conf), _f16_bits(mask), _f16_bits(proto)
         self._chk(self.L.yh_op_detect(self.h, _p(lb), _p(cb), _p(mb), _p(pb), n))
         self.n = n
+
+
+class Scene:
+    """RAII wrapper of yh_scene: append_scene's two compute dispatches (src/scene.rs:147-331) on the GPU."""
+
+    def __init__(self, width=640, height=480, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.yh_scene_create(device, width, height, C.byref(h))
+        if rc != OK:
+            raise YhError(rc, self.L.yh_scene_last_error(None).decode())
+        self.h, self.W, self.H = h, width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.yh_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise YhError(rc, self.L.yh_scene_last_error(self.h).decode())
+
+    def append(self, depth, cls_id, mode=COMPAT_STRICT):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        cls_id = np.ascontiguousarray(cls_id, np.uint8)
+        assert depth.shape == (self.H, self.W) and cls_id.shape == (self.H, self.W, 2)
+        self._chk(self.L.yh_scene_append(self.h, _p(depth), _p(cls_id), mode))
+
+    def append_classified(self, depth, frame_u32=None, frame_dev_ptr=None, mode=COMPAT_STRICT):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        assert depth.shape == (self.H, self.W)
+        if frame_dev_ptr is not None:
+            self._chk(self.L.yh_scene_append_classified(self.h, _p(depth), C.c_void_p(frame_dev_ptr), 1, mode))
+        else:
+            f = np.ascontiguousarray(frame_u32, np.uint32)
+            assert f.size == self.W * self.H
+            self._chk(self.L.yh_scene_append_classified(self.h, _p(depth), _p(f), 0, mode))
+
+    def read(self):
+        out = dict(map=np.zeros((self.H, self.W), np.uint32), world=np.zeros((self.H, self.W, 4), np.float32),
+                   conn0=np.zeros((self.H, self.W, 4), np.float32), conn1=np.zeros((self.H, self.W, 4), np.float32),
+                   balls=np.zeros((100, 4), np.float32))
+        self._chk(self.L.yh_scene_read(self.h, _p(out["map"]), _p(out["world"]), _p(out["conn0"]), _p(out["conn1"]), _p(out["balls"])))
+        return out
+
+    def time(self, reps=20):
+        ms = C.c_float()
+        self._chk(self.L.yh_scene_time(self.h, reps, C.byref(ms)))
+        return ms.value
 
 
 def tfl_validate(model_bytes):

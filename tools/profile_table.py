@@ -10,15 +10,22 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--size", type=int, default=550)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--top", type=int, default=200)
+ap.add_argument("--backbone", type=int, default=50)
+ap.add_argument("--precision", default="f16", choices=("f16", "fp8"))
+ap.add_argument("--tune", default="", help="comma-separated yh_tuning fields, e.g. tailfork=0,k1tile=0")
 a = ap.parse_args()
-eng = ya.Engine(input_size=a.size, max_batch=a.batch, use_graph=False)
+tune = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+eng = ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=a.batch, use_graph=False, tune=tune,
+                precision=ya.PRECISION_FP8 if a.precision == "fp8" else ya.PRECISION_F16)
 eng.load_weights(eng.generate_weights(1))
 rng = np.random.default_rng(0)
 eng.set_input(rng.integers(0, 256, (a.batch, a.size, a.size, 3), dtype=np.uint8))
+if a.precision == "fp8":
+    eng.fp8_calibrate()
 eng.evaluate(); eng.sync()
 prof = eng.profile(True, a.reps)
 tot = sum(p["ms"] for p in prof)
-print(f"batch {a.batch}: total {tot:.3f} ms over {len(prof)} launches -> {a.batch / tot * 1e3:.1f} fps (serialised, event-bracketed)")
+print(f"YOLACT-{a.size} R{a.backbone} {a.precision} batch {a.batch}: total {tot:.3f} ms over {len(prof)} launches -> {a.batch / tot * 1e3:.1f} fps (serialised, event-bracketed)")
 by = {}
 for p in prof:
     d = by.setdefault(p["name"].split(":")[0], [0.0, 0.0, 0.0, 0])
