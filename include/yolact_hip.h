@@ -87,7 +87,8 @@ typedef struct yh_tuning {
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
-    int32_t tfl_graph;       /* TFLite path: hipGraph replay of the plan (1) */
+    int32_t tfl_graph;       /* TFLite path: 0 eager launches, 1 hipGraph replay of the plan, 2 the same with a 4-byte memset on a
+                              * second stream captured beside it, so that the graph is not single-branch (default 2) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0: one stream,
                               * so the captured step is a single-branch graph */
     int32_t reserved[6];     /* -1 */

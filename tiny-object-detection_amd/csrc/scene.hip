@@ -8,7 +8,8 @@
 // undefined): every stage completes over the whole frame before the next starts (one launch per stage); texel (x, y)
 // is read for pixel (x, y); squares are products; a bump whose sigmoid base is not positive adds nothing; ball
 // centroids are exact integer means. Integer outputs and every float are bit-identical to the oracle: one IEEE
-// operation per operator (-ffp-contract=off, explicit _rn intrinsics for sqrt and division).
+// operation per operator (-ffp-contract=off; sqrtf and / are correctly rounded in HIP by default, unlike __fsqrt_rn,
+// which maps to the native approximate instruction).
 // HBM / atomic-bound byte work: one lane per pixel, 8x8 workgroups as the dispatch the reference uses; the height map
 // is built with atomicMax on 32-bit words as the shader's imageAtomicMax does.
 #include <hip/hip_runtime.h>
@@ -51,7 +52,7 @@ __device__ __forceinline__ void bump(const SceneParams& p, int px, int py, float
             const int x = px - L + lx, y = py - L + ly;
             if (x > 0 && y > 0 && x < p.W - 1 && y < p.H - 1) {
                 const int dx = px - x, dy = py - y;
-                const float prox = __fsqrt_rn((float)(dx * dx + dy * dy));
+                const float prox = __builtin_sqrtf((float)(dx * dx + dy * dy));
                 const float e = __fsub_rn(__fmul_rn(C2, prox), 1.0f);
                 const float y_add = __fdiv_rn(val, __fadd_rn(1.0f, spec_expf(__fmul_rn(e, logC1))));
                 const uint32_t v = y_add >= 1.0f ? (uint32_t)y_add : 0u;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(64) void scene_cloud(const SceneParams p) {
     const size_t i = (size_t)y * p.W + x;
     const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
     const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
-    const float cy = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(ty, ty))));
-    const float cx = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(1.0f, __fmul_rn(tx, tx))));
+    const float cy = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(ty, ty))));
+    const float cx = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(tx, tx))));
     const float d = __fmul_rn(__fmul_rn((float)p.depth[i], cy), cx);
     const int dic = (int)__fdiv_rn(__fmul_rn((float)p.H, d), SC_MAX_DEPTH);
     int cls, id;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64) void scene_conn1(const SceneParams p) {
             // returns world(0, 0) whoever the neighbour is; SANE: the neighbour's own position
             const float4 o = p.world[p.mode == 0 ? 0 : (size_t)qy * p.W + qx];
             const float dx = __fsub_rn(me.x, o.x), dy = __fsub_rn(me.y, o.y), dz = __fsub_rn(me.z, o.z);
-            v[k] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            v[k] = __builtin_sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
         }
     }
     p.conn1[i] = make_float4(v[0], v[1], v[2], v[3]);

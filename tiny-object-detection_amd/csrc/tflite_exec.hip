@@ -290,7 +290,10 @@ struct yh_tfl {
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
     hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
-    int use_dot = 1, use_graph = 1;   // yh_tuning.tfl_dot / tfl_graph
+    int use_dot = 1, use_graph = 2;   // yh_tuning.tfl_dot / tfl_graph
+    hipStream_t side = nullptr;       // tfl_graph = 2: carries the second branch of the captured graph
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* side_word = nullptr;
     // classify scratch
     uint32_t *frame_dev = nullptr, *codes_dev = nullptr, *stitch_dev = nullptr;
     uint8_t* tiles_dev = nullptr;
@@ -549,7 +552,14 @@ int run_plan(yh_tfl* h) {
     if (!h->gexec) {
         hipGraph_t g = nullptr;
         TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+        if (h->use_graph >= 2) {   // a second branch: the runtime then replays the graph node by node (see above)
+            TCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            TCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            TCHK(h, hipMemsetAsync(h->side_word, 0, 4, h->side));
+            TCHK(h, hipEventRecord(h->ev_join, h->side));
+        }
         const int rc = enqueue_plan(h);
+        if (h->use_graph >= 2 && !rc) TCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         const hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
@@ -602,7 +612,9 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     auto bail = [&](int rc) { g_tfl_create_error = h->err; yh_tfl_destroy(h); return rc; };
     if (!h->m.parse(h->file.data(), h->file.size())) { h->err = "tflite parse: " + h->m.error; return bail(YH_EWEIGHTS); }
     if (h->m.inputs.size() != 1) { h->err = "expected exactly one graph input"; return bail(YH_EINVAL); }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "device setup failed"; return bail(YH_EHIP); }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&h->side_word, 16) != hipSuccess) { h->err = "device setup failed"; return bail(YH_EHIP); }
     int rc = prepare(h);
     if (rc) return bail(rc);
     *out = h;
@@ -614,6 +626,10 @@ void yh_tfl_destroy(yh_tfl* h) {
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side_word) hipFree(h->side_word);
     for (size_t i = 0; i < h->tens.size(); ++i) if (h->tens[i] && !(i < h->alias.size() && h->alias[i])) hipFree(h->tens[i]);
     for (void* p : h->extra) hipFree(p);
     void* scratch[] = { h->frame_dev, h->codes_dev, h->stitch_dev, h->tiles_dev, h->rs_tmp, h->cells_dev, h->diverged_dev };
