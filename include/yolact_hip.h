@@ -81,14 +81,16 @@ typedef struct yh_tuning {
     int32_t stemfuse;        /* fused stem + max pool (1); creation time only */
     int32_t prefuse;         /* preprocessing inside the stem's patch loader (1); creation time only */
     int32_t headmerge;       /* the shared head as one multi-level launch per conv (1); creation time only */
-    int32_t upfuse;          /* bilinear x2 upsamples computed inside the consuming conv (1); creation time only */
+    int32_t upfuse;          /* FPN top-down upsamples evaluated in the lateral conv's epilogue instead of a kernel and a
+                              * tensor of their own (1); creation time only */
     int32_t k1_generic;      /* the generic softmax/candidate kernel also for 81 classes (0) */
     int32_t ablate;          /* timing only: bit 0 / bit 1 drop the activation / weight stream (results are garbage) */
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
-    int32_t tfl_graph;       /* TFLite path: 0 eager launches, 1 hipGraph replay of the plan, 2 the same with a 4-byte memset on a
-                              * second stream captured beside it, so that the graph is not single-branch (default 2) */
+    int32_t tfl_graph;       /* TFLite path: 0 eager launches (default; within 1 % of the graph forms), 1 hipGraph replay of the
+                              * plan, 2 the same with a 4-byte memset on a second stream captured beside it (not single-branch:
+                              * the form rocprofv3's kernel tracing can replay) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0: one stream,
                               * so the captured step is a single-branch graph */
     int32_t reserved[6];     /* -1 */

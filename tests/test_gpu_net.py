@@ -199,6 +199,30 @@ def test_batch_of_two_equals_two_singles(setup, golden_dir):
             assert np.abs(first[i] - both[i][f]).max() <= 0.02 * max(1.0, np.abs(both[i][f]).max())
 
 
+@pytest.mark.parametrize("S2,n", [(128, 2), (145, 1), (224, 3)])
+def test_fpn_upsample_in_the_lateral_epilogue_is_bitwise_the_two_kernel_form(built, S2, n):
+    """tune.upfuse (default): lat4 / lat3 evaluate the bilinear resize of the lower FPN level in their epilogue (also in
+    the split-K reduce that small batches take) instead of reading a materialised up5 / up4: every tensor downstream
+    must keep its bits. Sizes cover even and odd level edges (16 -> 8 -> 4, 19 -> 10 -> 5, 28 -> 14 -> 7)."""
+    import yolact_amd as ya
+    img = np.random.default_rng(S2).integers(0, 256, (n, S2, S2, 3), dtype=np.uint8)
+    outs = []
+    for upfuse in (1, 0):
+        eng = ya.Engine(input_size=S2, max_batch=n, use_graph=False, conf_thresh=THRESH, tune=dict(upfuse=upfuse))
+        eng.load_weights(eng.generate_weights(1))
+        eng.set_input(img)
+        eng.evaluate()
+        names = [p["name"] for p in eng.profile(with_tail=False, reps=1)]
+        assert any(n_.startswith("bilinear_f16:up") for n_ in names) == (upfuse == 0)
+        outs.append([eng.tensor(t) for t in ("lat5", "lat4", "lat3", "p3")] + [eng.output(i) for i in range(4)])
+        if upfuse:
+            with pytest.raises(ya.YhError):
+                eng.tensor("up5")                       # fused away (debug_tensors = 1 materialises it)
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_graph_replay_equals_eager(built, golden_dir):
     import yolact_amd as ya
     img = _frames(golden_dir)

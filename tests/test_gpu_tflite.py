@@ -104,6 +104,32 @@ def test_full_size_mobilenetv2_yolact_graph(built, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_graph_replay_forms_equal_eager_over_200_replays(built, mode):
+    """yh_tuning.tfl_graph = 1 (the plan as one single-branch hipGraph) and 2 (with a second captured branch, the form
+    rocprofv3's kernel tracing can replay: DESIGN.md §8): 200 replays on changing inputs, every output equal to the eager
+    executor's bit for bit."""
+    import yolact_amd as ya
+    rng = np.random.default_rng(5)
+    model = M.mobilenetv2_yolact(rng)
+    buf = bytes(B.serialize(model))
+    eager, graph = ya.TfliteEngine(buf, tune=dict(tfl_graph=0)), ya.TfliteEngine(buf, tune=dict(tfl_graph=mode))
+    for it in range(200):
+        x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
+        for e in (eager, graph):
+            e.set_input(x)
+            e.invoke()
+        if it % 20 == 0 or it == 199:
+            for k in range(5):
+                assert np.array_equal(eager.output(k), graph.output(k)), (it, k)
+    frame = (rng.integers(0, 256, (480, 640, 3), dtype=np.uint32) * np.array([1 << 24, 1 << 16, 1 << 8], np.uint32)).sum(-1).astype(np.uint32).reshape(-1)
+    fa, fb = frame.copy(), frame.copy()
+    eager.classify_frame(fa, 640, 480, ya.COMPAT_SANE)
+    graph.classify_frame(fb, 640, 480, ya.COMPAT_SANE)
+    assert np.array_equal(fa, fb)
+    eager.close(); graph.close()
+
+
 def test_classify_through_a_tflite_model(built, oracle, golden_dir):
     """Yolact::classify (yolact.rs:192-234) with a .tflite in the middle: pre-processing, two
     invokes, output-4 dequantisation (yolact.rs:177), postprocess, stitch, resize back."""

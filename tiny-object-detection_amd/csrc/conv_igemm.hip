@@ -41,6 +41,40 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 //              leaves the level (the shared prediction head as one launch over the whole pyramid).
 // EPI: the epilogue's f32 staging image covers TM / EPI rows at a time (a 256 x 256 tile's does not
 //      fit in LDS at once).
+// Residual of output row m, channels ch .. ch + 7: a plain load, or (res_up) the bilinear resize of the lower-resolution
+// tensor evaluated at this row's pixel, one IEEE operation per operator as in bilinear_f16 (elementwise.hip; this file is
+// built with contraction on, hence the pragma), rounded to f16 like the tensor it replaces.
+__device__ __forceinline__ half8 bilinear_residual(const ConvParams& p, int m, int ch);
+__device__ __forceinline__ half8 load_residual(const ConvParams& p, int m, int ch, long long ro) {
+    if (!p.res_up) return *(const half8*)(p.res + ro);
+    return bilinear_residual(p, m, ch);
+}
+__device__ __forceinline__ half8 bilinear_residual(const ConvParams& p, int m, int ch) {
+#pragma clang fp contract(off)
+    const int PQ = p.P * p.Q, n = m / PQ, rem = m - n * PQ, oy = rem / p.Q, ox = rem - oy * p.Q;
+    const float sy = (float)p.res_h / (float)p.P, sx = (float)p.res_w / (float)p.Q;
+    float fy = ((float)oy + 0.5f) * sy - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    float fx = ((float)ox + 0.5f) * sx - 0.5f;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, y1 = y0 + 1 < p.res_h ? y0 + 1 : p.res_h - 1;
+    const int x0 = (int)fx, x1 = x0 + 1 < p.res_w ? x0 + 1 : p.res_w - 1;
+    const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+    const half_t* rb = p.res + n * p.res_img_stride + ch;
+    const half8 p00 = *(const half8*)(rb + ((long long)y0 * p.res_w + x0) * p.ldres);
+    const half8 p01 = *(const half8*)(rb + ((long long)y0 * p.res_w + x1) * p.ldres);
+    const half8 p10 = *(const half8*)(rb + ((long long)y1 * p.res_w + x0) * p.ldres);
+    const half8 p11 = *(const half8*)(rb + ((long long)y1 * p.res_w + x1) * p.ldres);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float top = hx * (float)p00[e] + lx * (float)p01[e];
+        const float bot = hx * (float)p10[e] + lx * (float)p11[e];
+        o[e] = (half_t)(hy * top + ly * bot);
+    }
+    return o;
+}
+
 template <int MT, class ACC>
 __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC c) {
     if constexpr (MT == 32) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -234,7 +268,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             const int m = m_tile * TM + pass * RPP + rr;
             long long yo, ro;
             offsets(m < p.M ? m : 0, yo, ro);
-            rv0[pass] = *(const half8*)(p.res + ro);
+            rv0[pass] = load_residual(p, m < p.M ? m : 0, ch, ro);
         }
     }
 
@@ -438,7 +472,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                 const int m = m_tile * TM + h * EROWS + pass * RPP + rr;
                 long long yo, ro;
                 offsets(m < p.M ? m : 0, yo, ro);
-                rv[pass] = *(const half8*)(p.res + ro);
+                rv[pass] = load_residual(p, m < p.M ? m : 0, ch, ro);
             }
         }
         if (EPI == 1 || wm / WMG == h) {
@@ -694,7 +728,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
         ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
     }
     if (p.res) {
-        const half8 rv = *(const half8*)(p.res + ro);
+        const half8 rv = load_residual(p, m, ch, ro);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
     }

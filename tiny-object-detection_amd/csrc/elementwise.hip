@@ -58,41 +58,57 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict
 }
 
 // Bilinear resize, align_corners = false: src = (dst + 0.5) * in/out - 0.5 clamped at 0.
-// grid = (ceil(wo * c8 / 256), ho, n); the row coordinates are wave-uniform.
+// grid = (ceil(wo * c8 / 256), ceil(ho / BIL_ROWS), n): a lane produces BIL_ROWS output rows of one 8-channel group
+// (their 4 * BIL_ROWS source loads are all in flight before the first use: the kernel is a 624 MB write stream at the
+// protonet's x2 upsample and one 16-byte store per lane left the memory pipeline mostly idle).
+#define BIL_ROWS 4
 __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                     int h, int w, int c8, int ho, int wo,
                                                     long long x_img_stride, long long y_img_stride, uint8_t* __restrict__ y8, float y8_inv) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= wo * c8) return;
-    const int ox = t / c8, cg = t - ox * c8, oy = blockIdx.y, b = blockIdx.z;
+    const int ox = t / c8, cg = t - ox * c8, b = blockIdx.z, oy0 = blockIdx.y * BIL_ROWS;
     const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
-    float fy = ((float)oy + 0.5f) * sy - 0.5f;
-    fy = fy < 0.0f ? 0.0f : fy;
     float fx = ((float)ox + 0.5f) * sx - 0.5f;
     fx = fx < 0.0f ? 0.0f : fx;
-    const int y0 = (int)fy, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
     const int x0 = (int)fx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
-    const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+    const float lx = fx - (float)x0, hx = 1.0f - lx;
     const half_t* xb = x + b * x_img_stride + cg * 8;
     const int c = c8 * 8;
-    const half8 p00 = *(const half8*)(xb + ((long long)y0 * w + x0) * c);
-    const half8 p01 = *(const half8*)(xb + ((long long)y0 * w + x1) * c);
-    const half8 p10 = *(const half8*)(xb + ((long long)y1 * w + x0) * c);
-    const half8 p11 = *(const half8*)(xb + ((long long)y1 * w + x1) * c);
-    half8 o;
+    half8 p00[BIL_ROWS], p01[BIL_ROWS], p10[BIL_ROWS], p11[BIL_ROWS];
+    float ly[BIL_ROWS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float top = hx * (float)p00[e] + lx * (float)p01[e];
-        const float bot = hx * (float)p10[e] + lx * (float)p11[e];
-        o[e] = (half_t)(hy * top + ly * bot);
+    for (int r = 0; r < BIL_ROWS; ++r) {
+        const int oy = oy0 + r < ho ? oy0 + r : ho - 1;   // (rows past the end recompute the last row and are not stored)
+        float fy = ((float)oy + 0.5f) * sy - 0.5f;
+        fy = fy < 0.0f ? 0.0f : fy;
+        const int y0 = (int)fy, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        ly[r] = fy - (float)y0;
+        p00[r] = *(const half8*)(xb + ((long long)y0 * w + x0) * c);
+        p01[r] = *(const half8*)(xb + ((long long)y0 * w + x1) * c);
+        p10[r] = *(const half8*)(xb + ((long long)y1 * w + x0) * c);
+        p11[r] = *(const half8*)(xb + ((long long)y1 * w + x1) * c);
     }
-    const long long yo = b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8;
-    if (y) *(half8*)(y + yo) = o;
-    if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value)
-        unsigned lo = 0, hi = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv) << (8 * e); }
-        *(uint2*)(y8 + yo) = make_uint2(lo, hi);
+    for (int r = 0; r < BIL_ROWS; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= ho) break;
+        const float hy = 1.0f - ly[r];
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float top = hx * (float)p00[r][e] + lx * (float)p01[r][e];
+            const float bot = hx * (float)p10[r][e] + lx * (float)p11[r][e];
+            o[e] = (half_t)(hy * top + ly[r] * bot);
+        }
+        const long long yo = b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8;
+        if (y) *(half8*)(y + yo) = o;
+        if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value)
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv) << (8 * e); }
+            *(uint2*)(y8 + yo) = make_uint2(lo, hi);
+        }
     }
 }
 
@@ -183,7 +199,7 @@ hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, 
 }
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
                            long long xs, long long ys, hipStream_t s, uint8_t* y8, float y8_inv) {
-    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)ho, (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
+    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)((ho + BIL_ROWS - 1) / BIL_ROWS), (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
     return hipGetLastError();
 }
 hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, const float* inv_scale_rows, hipStream_t s) {

@@ -67,6 +67,7 @@ struct Op {
     std::string label;     // "kernel_symbol:layer"
     Buf in, out, res;
     bool has_res = false;
+    bool res_up = false;   // the residual is the bilinear resize of the lower-resolution tensor `res` (ConvParams::res_up)
     int panel = -1;
     int stride = 1, pad = 0, act = 0, tanh_from = INT_MAX;
     int P = 0, Q = 0;      // output spatial
@@ -427,11 +428,26 @@ int build_graph_spec(yh_engine* h) {
         o.bytes_per_img = 2.0 * in.c * ((double)in.h * in.w + (double)out.h * out.w);
         h->ops.push_back(o);
     };
+    // FPN top-down: P'_i = lat_i + bilinear(P'_{i+1}). tune.upfuse (default): the upsampled tensor is never written -
+    // the lateral conv's epilogue evaluates the bilinear resize of the lower level at each output pixel (ConvParams::
+    // res_up), bit-identical to bilinear_f16 + residual; engines with debug_tensors = 1 keep the two-kernel form so that
+    // "up5" / "up4" can be read.
+    const bool upfuse = h->tune.upfuse && !h->cfg.debug_tensors;
+    if (upfuse) { h->fused_away.insert("up5"); h->fused_away.insert("up4"); }
+    auto lateral = [&](const char* name, const Buf& feat, const Buf& lat, const char* up_name, const Buf& lower, const Buf& upbuf) {
+        if (!upfuse) {
+            bil(up_name, lower, upbuf);
+            h->ops.push_back(conv_op(h, name, add_panel(h, { ci++ }), feat, lat, 1, 0, 0, &upbuf));
+            return;
+        }
+        Op o = conv_op(h, name, add_panel(h, { ci++ }), feat, lat, 1, 0, 0, &lower);
+        o.res_up = true;
+        o.bytes_per_img = 2.0 * ((double)feat.h * feat.w * feat.c + (double)lat.h * lat.w * lat.c + (double)lower.h * lower.w * lower.c);
+        h->ops.push_back(o);
+    };
     h->ops.push_back(conv_op(h, "lat5", add_panel(h, { ci++ }), cfeat[3], lat5, 1, 0, 0, nullptr));
-    bil("up5", lat5, up5);
-    h->ops.push_back(conv_op(h, "lat4", add_panel(h, { ci++ }), cfeat[2], lat4, 1, 0, 0, &up5));
-    bil("up4", lat4, up4);
-    h->ops.push_back(conv_op(h, "lat3", add_panel(h, { ci++ }), cfeat[1], lat3, 1, 0, 0, &up4));
+    lateral("lat4", cfeat[2], lat4, "up5", lat5, up5);
+    lateral("lat3", cfeat[1], lat3, "up4", lat4, up4);
     h->ops.push_back(conv_op(h, "p5", add_panel(h, { ci++ }), lat5, level(h->pyr, 2), 1, 1, 1, nullptr));
     h->ops.push_back(conv_op(h, "p4", add_panel(h, { ci++ }), lat4, level(h->pyr, 1), 1, 1, 1, nullptr));
     h->ops.push_back(conv_op(h, "p3", add_panel(h, { ci++ }), lat3, level(h->pyr, 0), 1, 1, 1, nullptr));
@@ -755,7 +771,8 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     p.ldw = pn.Kpad; p.ksteps = pn.Kpad / 64;
     p.ldy = o.out.c; p.ldres = o.has_res ? o.res.c : 0;
     const long long pq = (long long)o.P * o.Q;
-    p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res.img_stride == pq * o.res.c);
+    p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res_up || o.res.img_stride == pq * o.res.c);
+    if (o.res_up) { p.res_up = 1; p.res_h = o.res.h; p.res_w = o.res.w; }
     p.act = o.act; p.tanh_from = o.tanh_from;
     p.nlev = o.nlev;
     for (int l = 0; l < 5; ++l) { p.lev_start[l] = o.lev_start[l]; p.lev_h[l] = o.lev_h[l]; p.lev_w[l] = o.lev_w[l]; }

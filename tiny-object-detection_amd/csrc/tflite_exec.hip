@@ -290,7 +290,7 @@ struct yh_tfl {
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
     hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
-    int use_dot = 1, use_graph = 2;   // yh_tuning.tfl_dot / tfl_graph
+    int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph = 2: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* side_word = nullptr;
@@ -537,16 +537,16 @@ int enqueue_plan(yh_tfl* h) {
     return YH_OK;
 }
 
-// One invoke = one graph launch (yh_tuning.tfl_graph, default 1; 0 = eager launches): 5 % faster per invoke on the
-// 136-op model (1.09 vs 1.17 ms; the step is bound by kernel time, not by launches).
-// Round 1 shipped eager launches by default because `rocprofv3 --kernel-trace` crashed inside hipGraphLaunch on this
-// graph. Cause (round 2, profiles/r02_graph_replay_under_rocprofv3.md with the logs): not the plan. The HIP runtime
-// replays a SINGLE-BRANCH graph from AQL packets it pre-built at instantiation ("graph packet capture"), and rocprofv3's
-// queue interception faults on that path: the YOLACT engine's own step crashes the same way when captured without its
-// tail fork (yh_invoke), while every forked graph (yh_evaluate) is fine, and with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in
-// the environment both this graph and the engine's single-branch one replay 300 times under the profiler. Without
-// the profiler the graph replays cleanly (600 invokes). So graph replay is the default again; to profile a
-// single-branch graph, export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (tools/collect_profiles.sh does) or pass tfl_graph = 0.
+// yh_tuning.tfl_graph: 0 eager launches (default), 1 the plan as one captured hipGraph, 2 the same with a 4-byte memset
+// captured on a side stream beside it. Per invoke on the 136-op model (set_input + invoke + read output 4, median of 300):
+// eager 1.104 ms, graph 1.096 ms, two-branch graph 1.222 ms - the step is bound by kernel time, not by launches.
+// Round 1 shipped eager launches because `rocprofv3 --kernel-trace` crashed inside hipGraphLaunch on the graph. The cause
+// (round 2, profiles/r02_graph_replay_under_rocprofv3.md with the logs) is not the plan: the HIP runtime replays a
+// SINGLE-BRANCH graph from AQL packets it pre-built at instantiation, and rocprofv3's queue interception faults on that
+// path - the YOLACT engine's own step crashes the same way when captured without its tail fork, every forked capture is
+// fine, mode 2 here replays cleanly under the profiler, and so does mode 1 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.
+// Without the profiler mode 1 replays cleanly (600 invokes). Since the graph buys 0.7 % here, the default stays the form
+// that every tool can observe; both graph forms are tested (tests/test_gpu_tflite.py).
 int run_plan(yh_tfl* h) {
     if (!h->use_graph) return enqueue_plan(h);
     if (!h->gexec) {

@@ -23,6 +23,10 @@ struct ConvParams {
     const half_t* w;      // weight panel [coutPad][ldw]
     const float* bias;    // [coutPad] (zero padded)
     const half_t* res;    // residual or nullptr
+    // res_up: the residual is the bilinear resize (align_corners = false) of the lower-resolution tensor res
+    // [n][res_h][res_w][ldres] to this conv's P x Q output, computed in the epilogue and rounded to f16 first - the FPN
+    // top-down add without materialising the upsampled tensor (bit-identical to bilinear_f16 + a plain residual)
+    int res_up, res_h, res_w;
     half_t* y;            // output base
     const int2* rs_table; // small-C mode: (r, s) per 16-byte chunk index; r = 1<<20 marks padding
     long long x_img_stride, y_img_stride, res_img_stride; // elements per image
