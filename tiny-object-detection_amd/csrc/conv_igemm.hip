@@ -44,10 +44,13 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 // Residual of output row m, channels ch .. ch + 7: a plain load, or (res_up) the bilinear resize of the lower-resolution
 // tensor evaluated at this row's pixel, one IEEE operation per operator as in bilinear_f16 (elementwise.hip; this file is
 // built with contraction on, hence the pragma), rounded to f16 like the tensor it replaces.
+// RESUP is a template flag of the conv kernel: the bilinear path costs ~24 VGPRs while the accumulators are live, which
+// took the streaming 1x1 tiles from 4 to 3 waves per SIMD (-10 % on 25 launches) when it was a run-time branch.
 __device__ __forceinline__ half8 bilinear_residual(const ConvParams& p, int m, int ch);
+template <bool RESUP>
 __device__ __forceinline__ half8 load_residual(const ConvParams& p, int m, int ch, long long ro) {
-    if (!p.res_up) return *(const half8*)(p.res + ro);
-    return bilinear_residual(p, m, ch);
+    if constexpr (RESUP) { if (p.res_up) return bilinear_residual(p, m, ch); }
+    return *(const half8*)(p.res + ro);
 }
 __device__ __forceinline__ half8 bilinear_residual(const ConvParams& p, int m, int ch) {
 #pragma clang fp contract(off)
@@ -89,7 +92,7 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 //      lane); 16: v_mfma_f32_16x16x32_f16 (K = 32, 4 accumulators per lane: lane l holds output
 //      pixel l & 15 and channels 4 (l >> 4) .. + 3). Same FLOPs per cycle; on real data the chip
 //      holds a higher clock on the 16x16x32 shape (guide: DVFS give-back item 7).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false>
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             const int m = m_tile * TM + pass * RPP + rr;
             long long yo, ro;
             offsets(m < p.M ? m : 0, yo, ro);
-            rv0[pass] = load_residual(p, m < p.M ? m : 0, ch, ro);
+            rv0[pass] = load_residual<RESUP>(p, m < p.M ? m : 0, ch, ro);
         }
     }
 
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                 const int m = m_tile * TM + h * EROWS + pass * RPP + rr;
                 long long yo, ro;
                 offsets(m < p.M ? m : 0, yo, ro);
-                rv[pass] = load_residual(p, m < p.M ? m : 0, ch, ro);
+                rv[pass] = load_residual<RESUP>(p, m < p.M ? m : 0, ch, ro);
             }
         }
         if (EPI == 1 || wm / WMG == h) {
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
         ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
     }
     if (p.res) {
-        const half8 rv = load_residual(p, m, ch, ro);
+        const half8 rv = load_residual<true>(p, m, ch, ro);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
     }
@@ -837,6 +840,22 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         return hipGetLastError();
     }
     const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
+    if (p.res_up) {   // the FPN lateral convs (1x1, 256 output channels): the tiles pick_tile / plan_conv can give them
+        switch (tile) {
+            case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_64x64_S4: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, false, true>), grid, dim3(512), 0, stream, p); break;
+            case TILE_256x256: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 32, false, false, true>), grid, dim3(512), 0, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (tile) {
         case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2>), grid, dim3(256), 0, stream, p); break;

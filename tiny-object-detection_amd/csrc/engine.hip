@@ -665,6 +665,9 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // (the 64-channel 3x3 convs of layer 1 too: 590 -> 715 TFLOP/s - their LDS fill per MFMA is what binds them, and
     // four co-resident workgroups overlap it better than a double buffer inside two)
     if (k1 >= 3 && !ml && pn.k == 3 && pn.tile == TILE_64x256 && (M + 255) / 256 >= k1_min) return TILE_64x256_K1;
+    // 64-channel layers at small batch (layer 1 at batch 1: 75 tiles of 64 x 256 on 256 CUs): 64 x 64 tiles make four
+    // times the workgroups
+    if (tu.t64 && !ml && pn.tile == TILE_64x256 && (M + 255) / 256 < tu.plan_cus) return TILE_64x64_S3;
     if (pn.tile == TILE_128x128 && pn.Kpad >= 256) {
         const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
         if (b128 <= tu.plan_cus) return TILE_128x128_S3;
