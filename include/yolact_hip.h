@@ -202,7 +202,8 @@ int yh_rank_broadcast_weights(yh_engine* h, const void* id, int32_t rank, int32_
 /* interpreter.inputs()[0] + tensor_info(..).dims (src/yolact.rs:149-150): {max_batch,S,S,3}. */
 int yh_input_dims(const yh_engine* h, int32_t dims[4]);
 /* tensor_data_mut(in).copy_from_slice (src/yolact.rs:161-162): copies n frames of u8 RGB NHWC
- * from host memory into the engine-owned input buffer. */
+ * from host memory into the engine-owned input buffer. The caller's buffer is free again on return, whether it is
+ * pageable or pinned (the copy itself is asynchronous on the handle's stream). */
 int yh_set_input_u8(yh_engine* h, const uint8_t* rgb_host, int32_t n_frames);
 /* Same with frames already resident in device memory (bench path: inputs in HBM). */
 int yh_set_input_u8_device(yh_engine* h, const uint8_t* rgb_dev, int32_t n_frames);

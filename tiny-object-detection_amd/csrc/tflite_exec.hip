@@ -657,6 +657,11 @@ int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes) {
     if (nbytes != t.count() * t.elem()) return h->fail(YH_EINVAL, "input size mismatch");   // the reference only warns (yolact.rs:151-158)
     TCHK(h, hipSetDevice(h->dev));
     TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], data, nbytes, hipMemcpyHostToDevice, h->stream));
+    // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. From pageable memory the
+    // runtime has staged the bytes by now; from pinned / registered memory the DMA is still reading: wait for it.
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, data) == hipSuccess && at.type == hipMemoryTypeHost) TCHK(h, hipStreamSynchronize(h->stream));
+    else (void)hipGetLastError();
     return YH_OK;
 }
 int yh_tfl_invoke(yh_tfl* h) {
