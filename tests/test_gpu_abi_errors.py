@@ -85,3 +85,39 @@ def test_classify_argument_checks(built):
     eng.classify_frame(frame, 64, 48, ya.COMPAT_SANE)                  # tiny 64x48 frame works
     assert ((frame >> 24) <= 3).all()
     eng.close()
+
+
+def test_rccl_weight_broadcast_entry_points_on_one_gpu(built):
+    """The library's own RCCL path (yh_rccl_unique_id / yh_rank_broadcast_weights / yh_group_broadcast_weights), as far as
+    one GPU lets it run: librccl is opened, a communicator of one rank is created, the broadcast runs and the weights stay
+    usable. RCCL refuses two ranks on one device, so n > 1 is the driver's 8-GPU run (bench.py takes this path there, with
+    torch.distributed as the fallback if any rank fails)."""
+    import numpy as np
+    import yolact_amd as ya
+    eng = ya.Engine(input_size=128, max_batch=1, use_graph=False, conf_thresh=0.005)
+    with pytest.raises(ya.YhError) as e:
+        eng.rank_broadcast_weights(b"\0" * 128, 0, 1, 0)          # the root must hold weights first
+    assert e.value.code == ya.capi.ESTATE
+    blob = eng.generate_weights(seed=1)
+    eng.load_weights(blob)
+    img = np.random.default_rng(0).integers(0, 256, (1, 128, 128, 3), dtype=np.uint8)
+    eng.set_input(img); eng.evaluate()
+    before = [eng.output(i) for i in range(4)]
+    ident = ya.rccl_unique_id()
+    assert len(ident) == 128 and any(ident)
+    eng.rank_broadcast_weights(ident, 0, 1, 0)                   # ncclCommInitRank(1 rank) + ncclBroadcast + destroy
+    ya.group_broadcast_weights([eng], 0)                          # one handle: nothing to do, still validated
+    with pytest.raises(ya.YhError):
+        eng.rank_broadcast_weights(ident, 1, 1, 0)               # rank out of range
+    assert eng.weights_device_ptr()
+    eng.set_input(img); eng.evaluate()
+    for a, b in zip(before, [eng.output(i) for i in range(4)]):
+        assert np.array_equal(a, b)
+    # a second engine on the same device loads straight from the first one's device blob (what a non-root rank does
+    # with the bytes it received)
+    e2 = ya.Engine(input_size=128, max_batch=1, use_graph=False, conf_thresh=0.005)
+    e2.load_weights_device(eng.weights_device_ptr(), eng.weights_nbytes())
+    e2.set_input(img); e2.evaluate()
+    for a, b in zip(before, [e2.output(i) for i in range(4)]):
+        assert np.array_equal(a, b)
+    e2.close(); eng.close()
