@@ -256,3 +256,48 @@ def test_yolact700_r101_one_frame_vs_oracle(built, oracle):
     acc = bench.accuracy_vs_oracle(dets, fd)
     assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and (acc["mask_iou_all"] is None or acc["mask_iou_all"] >= 0.99), acc
     eng.close()
+
+
+# ---- configs[4] itself: YOLACT-700 ResNet-101 with fp8 operands (yh_config.precision = YH_PRECISION_FP8) ----
+def test_yolact700_r101_fp8_one_frame_vs_fp8_oracle(built, oracle):
+    """The fp8 forward at configs[4]'s geometry against the oracle's fp8 mode with the engine's calibrated scales (bounds
+    and their reasons: tests/test_gpu_fp8.py), the tail bit-exact on the engine's heads, and the
+    frame-slot independence of a batch of 3 (the 36 E4M3 launches take the 128 x 128 fp8 tile at this batch size)."""
+    import yolact_amd as ya
+    S7 = 700
+    eng = ya.Engine(input_size=S7, backbone=101, max_batch=3, use_graph=True, precision=ya.PRECISION_FP8)
+    blob = eng.generate_weights(seed=1)
+    eng.load_weights(blob)
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (3, S7, S7, 3), dtype=np.uint8)
+    eng.set_input(frames)
+    eng.fp8_calibrate()
+    layers = eng.fp8_layers()
+    assert len(layers) == 36 and {"l3b22_b", "l4b2_b", "p7", "proto3", "head_t"} <= {n for n, _ in layers}
+    eng.evaluate()
+    names = [p["name"] for p in eng.profile(with_tail=False, reps=1)]
+    assert sum(n.startswith("conv_igemm_fp8<") for n in names) == 36
+    heads = [eng.output(i) for i in range(4)]
+    dets = [eng.detections(f) for f in range(3)]
+    net = oracle.Net(101, S7, 81, blob=blob)
+    lay = {}
+    for name, sc in layers:
+        for nm in ([f"{name}{l}" for l in range(5)] if name == "head_t" else [name]):
+            lay[nm] = sc
+    net.set_fp8(lay)
+    want = net.forward(frames[1:2], f16=True)
+    for tn, a, b in zip(("loc", "conf", "mask", "proto"), heads, want):
+        mx = float(np.abs(a[1] - b[0]).max() / max(1.0, np.abs(b).max()))
+        rms = float(np.sqrt(((a[1] - b[0]) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+        assert mx <= (0.3 if tn == "mask" else 0.2) and rms <= 0.12, (tn, mx, rms)   # deeper than the 160-pixel R50 case: 36 chained E4M3 layers
+    pri = net.priors()
+    for f in range(3):
+        odets, omasks = oracle.detect(heads[0][f], heads[1][f], heads[2][f], heads[3][f], pri)
+        assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets[f][0]] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
+        assert np.array_equal(dets[f][1], omasks)
+    perm = np.array([2, 0, 1])
+    eng.set_input(frames[perm])
+    eng.evaluate()
+    for i in range(4):
+        assert np.array_equal(eng.output(i), heads[i][perm])
+    eng.close()
