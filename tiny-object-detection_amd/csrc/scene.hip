@@ -41,22 +41,49 @@ struct SceneParams {
     float4 *world, *conn0, *conn1;
     long long* ball_acc;          // [3][100]: sum x, sum y, count
     float4* balls;                // [100]
+    // the bump profiles, tabulated once per handle: a tap's height depends only on (val, dx, dy), and val is the pixel's
+    // ROW for terrain (pt_cloud.comp:116) or the constant 100 for robots (:122)
+    const uint32_t* terrain_tab;  // [H][20][20]
+    const uint32_t* robot_tab;    // [40][40]
 };
 
-__device__ __forceinline__ void bump(const SceneParams& p, int px, int py, float val, int L) {
+// height of one bump tap (pt_cloud.comp:55-73): val / (1 + C_1^(C_2 prox - 1)), truncated; 0 where the shader's pow() is undefined
+__device__ __forceinline__ uint32_t bump_tap(float val, int L, int lx, int ly) {
     const float C1 = __fsub_rn(__fdiv_rn(val, SC_BUMP_ERR), 1.0f), C2 = __fdiv_rn(2.0f, (float)L);
-    if (!(C1 > 0.0f)) return;
-    const float logC1 = spec_logf(C1);   // pow(C_1, e) = exp(e * log(C_1)): the logarithm does not depend on the tap
+    if (!(C1 > 0.0f)) return 0u;
+    const float logC1 = spec_logf(C1);   // pow(C_1, e) = exp(e * log(C_1))
+    const int dx = L - lx, dy = L - ly;  // pos - loc with loc = pos - L + (lx, ly)
+    const float prox = __builtin_sqrtf((float)(dx * dx + dy * dy));
+    const float e = __fsub_rn(__fmul_rn(C2, prox), 1.0f);
+    const float y_add = __fdiv_rn(val, __fadd_rn(1.0f, spec_expf(__fmul_rn(e, logC1))));
+    return y_add >= 1.0f ? (uint32_t)y_add : 0u;
+}
+
+// one lane per table entry: terrain [H][2L][2L] with val = row, robot [2L][2L] with val = 100
+__global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t* robot, int H) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int nt = H * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM, nr = 4 * SC_BOT_NORM * SC_BOT_NORM;
+    if (t < nt) {
+        const int y = t / (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM), r = t % (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM);
+        terrain[t] = bump_tap((float)y, SC_TERRAIN_NORM, r / (2 * SC_TERRAIN_NORM), r % (2 * SC_TERRAIN_NORM));
+    } else if (t - nt < nr) {
+        const int r = t - nt;
+        robot[r] = bump_tap(SC_BOT_AVOID, SC_BOT_NORM, r / (2 * SC_BOT_NORM), r % (2 * SC_BOT_NORM));
+    }
+}
+
+// pt_cloud.comp:44-76 with the tap heights read from the table ([lx][ly]). imageAtomicMax is a max: a tap that does not
+// exceed what a read of the map already shows cannot change it (the map only grows within the launch, from the zeros the
+// memset left: whatever age the value read has, it is a lower bound of the cell), so only the other taps issue the atomic -
+// most taps of overlapping bumps lose, and the kernel stops being bound by 150 M atomics per frame.
+__device__ __forceinline__ void bump(const SceneParams& p, int px, int py, const uint32_t* tab, int L) {
     for (int lx = 0; lx < 2 * L; ++lx)
         for (int ly = 0; ly < 2 * L; ++ly) {
             const int x = px - L + lx, y = py - L + ly;
             if (x > 0 && y > 0 && x < p.W - 1 && y < p.H - 1) {
-                const int dx = px - x, dy = py - y;
-                const float prox = __builtin_sqrtf((float)(dx * dx + dy * dy));
-                const float e = __fsub_rn(__fmul_rn(C2, prox), 1.0f);
-                const float y_add = __fdiv_rn(val, __fadd_rn(1.0f, spec_expf(__fmul_rn(e, logC1))));
-                const uint32_t v = y_add >= 1.0f ? (uint32_t)y_add : 0u;
-                if (v) atomicMax(p.map + (size_t)y * p.W + x, v);
+                const uint32_t v = tab[lx * 2 * L + ly];
+                uint32_t* cell = p.map + (size_t)y * p.W + x;
+                if (v > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, v);
             }
         }
 }
@@ -82,14 +109,14 @@ __global__ __launch_bounds__(64) void scene_cloud(const SceneParams p) {
     int action = cls;
     if (action > 1) action = action - 1;
     const int nx = x, ny = p.H - dic;
-    if (action == 0) bump(p, nx, ny, (float)y, SC_TERRAIN_NORM);
+    if (action == 0) bump(p, nx, ny, p.terrain_tab + (size_t)y * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM, SC_TERRAIN_NORM);
     else if (action == 2) {
         if (id < 100) {
             atomicAdd((unsigned long long*)p.ball_acc + id, (unsigned long long)(long long)nx);
             atomicAdd((unsigned long long*)p.ball_acc + 100 + id, (unsigned long long)(long long)ny);
             atomicAdd((unsigned long long*)p.ball_acc + 200 + id, 1ull);
         }
-    } else bump(p, nx, ny, SC_BOT_AVOID, SC_BOT_NORM);
+    } else bump(p, nx, ny, p.robot_tab, SC_BOT_NORM);
 }
 
 __global__ void scene_balls(const SceneParams p) {
@@ -163,6 +190,7 @@ struct yh_scene {
     uint32_t* map = nullptr;
     float4 *world = nullptr, *conn0 = nullptr, *conn1 = nullptr, *balls = nullptr;
     long long* ball_acc = nullptr;
+    uint32_t *terrain_tab = nullptr, *robot_tab = nullptr;
     bool ran = false;
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -174,6 +202,7 @@ int run_scene(yh_scene* h, const uint16_t* depth_dev, const uint8_t* cls_dev, co
     SceneParams p;
     p.depth = depth_dev; p.cls_id = cls_dev; p.frame = frame_dev; p.frame_mode = frame_mode;
     p.W = h->W; p.H = h->H; p.mode = mode;
+    p.terrain_tab = h->terrain_tab; p.robot_tab = h->robot_tab;
     p.map = h->map; p.world = h->world; p.conn0 = h->conn0; p.conn1 = h->conn1; p.ball_acc = h->ball_acc; p.balls = h->balls;
     const size_t npx = (size_t)h->W * h->H;
     SCHK(h, hipMemsetAsync(h->map, 0, npx * 4, h->stream));
@@ -214,6 +243,13 @@ int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** ou
     if (e == hipSuccess) e = hipMalloc((void**)&h->conn1, npx * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&h->balls, 100 * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&h->ball_acc, 300 * sizeof(long long));
+    const size_t nt = (size_t)height * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM, nr = 4 * SC_BOT_NORM * SC_BOT_NORM;
+    if (e == hipSuccess) e = hipMalloc((void**)&h->terrain_tab, nt * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->robot_tab, nr * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(scene_tables, dim3((unsigned)((nt + nr + 255) / 256)), dim3(256), 0, h->stream, h->terrain_tab, h->robot_tab, height);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) { g_scene_create_error = std::string("scene setup: ") + hipGetErrorString(e); yh_scene_destroy(h); return YH_EHIP; }
     *out = h;
     return YH_OK;
@@ -223,7 +259,7 @@ void yh_scene_destroy(yh_scene* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = { h->depth, h->cls_id, h->frame, h->map, h->world, h->conn0, h->conn1, h->balls, h->ball_acc };
+    void* bufs[] = { h->depth, h->cls_id, h->frame, h->map, h->world, h->conn0, h->conn1, h->balls, h->ball_acc, h->terrain_tab, h->robot_tab };
     for (void* b : bufs) if (b) hipFree(b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
