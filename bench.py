@@ -473,6 +473,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--torch-broadcast", action="store_true",
+                    help="replicate the weights with torch.distributed.broadcast instead of the library's own RCCL broadcast (yh_rank_broadcast_weights)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N > 1 path on a single-GPU box: every rank uses cuda:0 and the "
                          "weight broadcast goes over gloo (RCCL refuses two ranks on one device); not a measurement")
@@ -501,7 +503,7 @@ def main():
     # weights: generated once on rank 0, replicated with ONE RCCL broadcast over xGMI
     src = ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=1, use_graph=False, device=local_rank)
     nbytes = src.weights_nbytes()
-    how = replicate_weights(ya, torch, dist, rank, world, local_rank, src, a.seed, use_library=not a.rehearse_on_one_gpu)
+    how = replicate_weights(ya, torch, dist, rank, world, local_rank, src, a.seed, use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast))
     blob_ptr = src.weights_device_ptr()
 
     dt, prof, flops, ndet, aux = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,

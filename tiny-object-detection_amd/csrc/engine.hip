@@ -1348,16 +1348,17 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
-Rccl* rccl() {   // opened once per process; a failed open is remembered with its reason
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
+void rccl_open(Rccl& r);
+Rccl* rccl() {   // opened once per process (thread-safe: C++11 static initialisation); a failed open is remembered with its reason
+    static Rccl r = [] { Rccl x; rccl_open(x); return x; }();
+    return &r;
+}
+void rccl_open(Rccl& r) {
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
-    if (!r.lib) { r.err = std::string("dlopen librccl.so: ") + (dlerror() ? dlerror() : "not found"); return &r; }
+    if (!r.lib) { const char* why = dlerror(); r.err = std::string("dlopen librccl.so: ") + (why ? why : "not found"); return; }
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl.so lacks ") + n; return p; };
     r.GetUniqueId = (int (*)(RcclId*))sym("ncclGetUniqueId");
     r.CommInitRank = (int (*)(rccl_comm*, int, RcclId, int))sym("ncclCommInitRank");
@@ -1367,9 +1368,8 @@ Rccl* rccl() {   // opened once per process; a failed open is remembered with it
     r.GroupStart = (int (*)())sym("ncclGroupStart");
     r.GroupEnd = (int (*)())sym("ncclGroupEnd");
     r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-    return &r;
 }
-std::string rccl_msg(Rccl* r, const char* what, int rc) { return std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "error") ; }
+extern "C++" std::string rccl_msg(Rccl* r, const char* what, int rc) { return std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "error"); }
 // after the receive: validate and repack exactly as yh_load_weights_device does
 int adopt_received_blob(yh_engine* h) {
     std::vector<uint8_t> host(h->blob_bytes);
