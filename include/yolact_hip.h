@@ -91,8 +91,8 @@ typedef struct yh_tuning {
     int32_t tfl_graph;       /* TFLite path: 0 eager launches (default; within 1 % of the graph forms), 1 hipGraph replay of the
                               * plan, 2 the same with a 4-byte memset on a second stream captured beside it (not single-branch:
                               * the form rocprofv3's kernel tracing can replay) */
-    int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0: one stream,
-                              * so the captured step is a single-branch graph */
+    int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet: 1 always, 0 never (the
+                              * captured step is then a single-branch graph); default: from batch 4 on */
     int32_t reserved[6];     /* -1 */
 } yh_tuning;
 

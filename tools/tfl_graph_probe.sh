@@ -1,6 +1,7 @@
 #!/bin/bash
-# VERDICT r1 item 5 - what makes rocprofv3 --kernel-trace crash on a replayed graph, and does a second captured branch
-# avoid it? Each run is its own process with its own timeout; logs in gpurun_out/tflgraph/.
+# Graph replay under rocprofv3 --kernel-trace (profiles/r02_graph_replay_under_rocprofv3.md): every capture
+# this library makes must replay under the profiler - forked captures as they are, single-branch ones through the second
+# branch they get when a rocprofiler-sdk tool is loaded. Each run is its own process with its own timeout.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/tflgraph
 mkdir -p $OUT
@@ -9,15 +10,11 @@ run() {  # name, then the program and its arguments
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/p_$name -o run --output-format csv -- "$@" > $OUT/$name.log 2>&1
   echo "exit=$?" >> $OUT/$name.log
-  echo "== $name: $(grep -E 'graph replays|invoke 224|classify 640|exit=' $OUT/$name.log | tr '\n' ' ')"
-  if [ "$name" = "E_tflite_graph_two_branches" ]; then cp "$(find $OUT/p_$name -name '*kernel_stats.csv' | sort | tail -1)" $OUT/r02_tflite_rocprofv3_kernel_stats.csv 2>/dev/null; fi
+  echo "== $name: $(grep -E 'graph replays|invoke 224|classify 640|ms/step|exit=' $OUT/$name.log | tr '\n' ' ')"
   rm -rf $OUT/p_$name
 }
-run E_tflite_graph_two_branches python3 $R/tools/time_tflite.py --graph 2 --invokes 300
-run F_engine_invoke_two_branches python3 $R/tools/graph_probe.py invoke 300
-run G_tflite_graph_single_branch python3 $R/tools/time_tflite.py --graph 1 --invokes 50
-echo "== no profiler:"
-python3 $R/tools/time_tflite.py --graph 2 --invokes 300 | tail -2
-python3 $R/tools/time_tflite.py --graph 1 --invokes 300 | tail -2
-python3 $R/tools/time_tflite.py --graph 0 --invokes 300 | tail -2
+run H_engine_invoke_batch2 python3 $R/tools/graph_probe.py invoke 300
+run I_engine_evaluate_batch2_unforked python3 $R/tools/graph_probe.py evaluate 300
+run J_time_steps_batch1_and_4 python3 $R/tools/time_steps.py 1 4
+run K_tflite_graph1_single_branch_capture python3 $R/tools/time_tflite.py --graph 1 --invokes 100
 echo done
