@@ -406,10 +406,19 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, ba
     return r
 
 
+VERBOSE = False
+
+
+def progress(msg):
+    """--verbose: phase markers on stderr (the JSON line stays the only thing on stdout)."""
+    if VERBOSE:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50,
-               precision="f16"):
+               precision="f16", tune=None):
     eng = ya.Engine(input_size=size, backbone=backbone, max_batch=batch, use_graph=True, device=local_rank,
-                    precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16)
+                    precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16, tune=tune)
     eng.load_weights_device(blob_dev_ptr, blob_nbytes)
     g = torch.Generator(device=f"cuda:{local_rank}")
     start, _ = shard_frames(world * batch, world, rank)
@@ -425,9 +434,11 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
     def step(i):
         eng.set_input_device(bufs[i % ring].data_ptr(), batch)
         eng.evaluate()
+    progress(f"batch {batch}: warmup")
     for i in range(warmup):
         step(i)
     eng.sync()
+    progress(f"batch {batch}: timed steps")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(); eng.sync()
@@ -439,23 +450,30 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
     dt = max_over_ranks(dist, dt, f"cuda:{local_rank}")
     if dist is not None:
         dist.barrier()
+    progress(f"batch {batch}: timed steps done, per-launch profile")
     prof = eng.profile(with_tail=True, reps=3) if rank == 0 else None
+    progress(f"batch {batch}: detections")
     ndet = sum(len(eng.detections(f, want_masks=False)[0]) for f in range(min(batch, 4))) if rank == 0 else 0
     flops = eng.flops_per_frame()
     aux = {}
     if rank == 0:
         host = bufs[0].cpu().numpy()
         aux["host_frame"] = host[:1]
+        progress(f"batch {batch}: latency_stats")
         aux["latency"] = latency_stats(eng)
+        progress(f"batch {batch}: pcie_inclusive")
         aux["pcie_inclusive_fps"] = pcie_inclusive(eng, host)
         if batch == 1:
+            progress(f"batch {batch}: host_to_detections_latency")
             aux["host_to_detections_latency"] = host_to_detections_latency(eng, host)
+        progress(f"batch {batch}: final frame-0 detections")
         eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
         aux["dets_frame0"] = eng.detections(0, want_masks=True)
         aux["fp8_layers"] = eng.fp8_layers() if precision == "fp8" else None
     if dist is not None:
         dist.barrier()
     eng.close()
+    progress(f"batch {batch}: engine closed")
     return dt, prof, flops, ndet, aux
 
 
@@ -473,16 +491,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="phase markers on stderr")
+    ap.add_argument("--tune", default="", help="comma-separated yh_tuning fields for A/B measurements, e.g. tailfork=1,k1tile=0 (default: none)")
     ap.add_argument("--torch-broadcast", action="store_true",
                     help="replicate the weights with torch.distributed.broadcast instead of the library's own RCCL broadcast (yh_rank_broadcast_weights)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N > 1 path on a single-GPU box: every rank uses cuda:0 and the "
                          "weight broadcast goes over gloo (RCCL refuses two ranks on one device); not a measurement")
     a = ap.parse_args()
+    global VERBOSE
+    VERBOSE = a.verbose
 
     import numpy as np
     import torch
     import yolact_amd as ya
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)} or None
     rank, world, local_rank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if a.rehearse_on_one_gpu:
         local_rank = 0
@@ -507,12 +530,12 @@ def main():
     blob_ptr = src.weights_device_ptr()
 
     dt, prof, flops, ndet, aux = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
-                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone, precision=a.precision)
+                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune)
     extra = {}
     if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
         s1 = max(a.steps * 4, 40)
         dt1, prof1, _, _, aux1 = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
-                                         blob_ptr, nbytes, backbone=a.backbone, precision=a.precision)
+                                         blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune)
         if rank == 0:
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 {a.precision} {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),

@@ -88,11 +88,10 @@ typedef struct yh_tuning {
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
-    int32_t tfl_graph;       /* TFLite path: 0 eager launches (default; within 1 % of the graph forms), 1 hipGraph replay of the
-                              * plan, 2 the same with a 4-byte memset on a second stream captured beside it (not single-branch:
-                              * the form rocprofv3's kernel tracing can replay) */
-    int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet: 1 always, 0 never (the
-                              * captured step is then a single-branch graph); default: from batch 4 on */
+    int32_t tfl_graph;       /* TFLite path: 0 eager launches (default, and the faster form: 1.10 vs 1.22 ms), 1 hipGraph replay
+                              * of the plan (captured with a second, one-node branch: DESIGN.md §8 on single-branch graphs) */
+    int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0 keeps them on
+                              * the main stream */
     int32_t reserved[6];     /* -1 */
 } yh_tuning;
 

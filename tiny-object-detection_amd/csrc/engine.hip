@@ -114,7 +114,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
-    r.tailfork = t.tailfork;   // -1: by batch size (enqueue_all)
+    r.tailfork = d(t.tailfork, 1);
     return r;
 }
 
@@ -868,31 +868,21 @@ int launch_op(yh_engine* h, const Op& o, int n) {
     return YH_OK;
 }
 
-// Is a rocprofiler-sdk tool (rocprofv3) loaded in this process? Process state, not configuration: no environment is read.
-bool profiler_attached() {
-    static const bool on = [] {
-        for (const char* lib : { "librocprofiler-sdk-tool.so", "librocprofiler-sdk-tool.so.1", "librocprofiler-sdk-tool.so.0" }) {
-            void* hnd = dlopen(lib, RTLD_NOLOAD | RTLD_LAZY);
-            if (hnd) { dlclose(hnd); return true; }
-        }
-        return false;
-    }();
-    return on;
-}
-
 int enqueue_all(yh_engine* h, int n, int with_tail) {
     // One stream, except that the tail's K1-K3 (softmax/append, per-class NMS, frame top-k: small latency-bound
     // grids that need only the head rows) fork onto the side stream underneath the protonet's convolutions and
     // join before the mask kernel (event record / wait: valid under stream capture).
-    // The fork pays from batch 4 on. Below that the step is bound by kernel count, and a captured step WITHOUT a fork is a
-    // single-branch graph, which the HIP runtime replays from AQL packets pre-built at instantiation: 0.751 vs 0.784 ms at
-    // batch 1, 1.010 vs 1.014 at 2, equal at 4 (tune.tailfork: 1 always, 0 never, default by batch size).
+    // The fork pays from batch 4 on and costs nothing below (tune.tailfork = 0 keeps the tail on the main stream).
+    //
+    // A capture WITHOUT a fork would be a single-branch graph, which the HIP runtime (ROCm 7.2) replays from AQL packets it
+    // pre-built at instantiation. That path is 4 % faster at batch 1 (0.751 vs 0.784 ms) and is NOT used: rocprofv3's
+    // kernel tracing crashes on it, and bench.py's batch-1 leg (host copies and reads between the replays, after an earlier
+    // engine's graphs had been destroyed) ended in a GPU memory access fault on it with kernels and arguments that are
+    // identical to the forked form's (profiles/r02_graph_replay_under_rocprofv3.md). Every capture that has no fork of its
+    // own therefore gets a second branch - a 4-byte memset captured on the side stream - and replays node by node.
     bool tail_forked = false;
-    const bool fork = h->tune.tailfork < 0 ? n >= 4 : h->tune.tailfork != 0;
-    // ... but rocprofv3's kernel tracing faults on exactly that replay path (profiles/r02_graph_replay_under_rocprofv3.md).
-    // When a rocprofiler-sdk tool is loaded in this process, a single-branch capture therefore gets a second branch - a
-    // 4-byte memset captured on the side stream - which makes the runtime replay it node by node.
-    const bool dummy_branch = h->capturing && !(with_tail && fork) && profiler_attached();
+    const bool fork = h->tune.tailfork != 0;
+    const bool dummy_branch = h->capturing && !(with_tail && fork);
     if (dummy_branch) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));

@@ -291,7 +291,7 @@ struct yh_tfl {
     std::vector<Prepared> plan;
     hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
     int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
-    hipStream_t side = nullptr;       // tfl_graph = 2: carries the second branch of the captured graph
+    hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* side_word = nullptr;
     // classify scratch
@@ -537,29 +537,29 @@ int enqueue_plan(yh_tfl* h) {
     return YH_OK;
 }
 
-// yh_tuning.tfl_graph: 0 eager launches (default), 1 the plan as one captured hipGraph, 2 the same with a 4-byte memset
-// captured on a side stream beside it. Per invoke on the 136-op model (set_input + invoke + read output 4, median of 300):
-// eager 1.104 ms, graph 1.096 ms, two-branch graph 1.222 ms - the step is bound by kernel time, not by launches.
-// Round 1 shipped eager launches because `rocprofv3 --kernel-trace` crashed inside hipGraphLaunch on the graph. The cause
+// yh_tuning.tfl_graph: 0 eager launches (default), 1 the plan as one captured hipGraph (with a 4-byte memset captured on
+// a side stream beside it, so that the graph has two branches). Per invoke on the 136-op model (set_input + invoke + read
+// output 4, median of 300): eager 1.104 ms, two-branch graph 1.222 ms, single-branch graph 1.096 ms - the step is bound by
+// kernel time, not by launches, and the one graph form that is not slower is the one that cannot ship:
+// round 1 shipped eager launches because `rocprofv3 --kernel-trace` crashed inside hipGraphLaunch on the graph. The cause
 // (round 2, profiles/r02_graph_replay_under_rocprofv3.md with the logs) is not the plan: the HIP runtime replays a
 // SINGLE-BRANCH graph from AQL packets it pre-built at instantiation, and rocprofv3's queue interception faults on that
-// path - the YOLACT engine's own step crashes the same way when captured without its tail fork, every forked capture is
-// fine, mode 2 here replays cleanly under the profiler, and so does mode 1 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.
-// Without the profiler mode 1 replays cleanly (600 invokes). Since the graph buys 0.7 % here, the default stays the form
-// that every tool can observe; both graph forms are tested (tests/test_gpu_tflite.py).
+// path - the YOLACT engine's own step crashes the same way when captured without a second branch, every forked capture is
+// fine, and so is the single-branch form with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0. The same replay path later produced a GPU
+// memory access fault WITHOUT the profiler (engine.hip, enqueue_all), so this library never builds a single-branch graph.
 int run_plan(yh_tfl* h) {
     if (!h->use_graph) return enqueue_plan(h);
     if (!h->gexec) {
         hipGraph_t g = nullptr;
         TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-        if (h->use_graph >= 2) {   // a second branch: the runtime then replays the graph node by node (see above)
+        {   // a second branch: the runtime then replays the graph node by node (see above)
             TCHK(h, hipEventRecord(h->ev_fork, h->stream));
             TCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
             TCHK(h, hipMemsetAsync(h->side_word, 0, 4, h->side));
             TCHK(h, hipEventRecord(h->ev_join, h->side));
         }
         const int rc = enqueue_plan(h);
-        if (h->use_graph >= 2 && !rc) TCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        if (!rc) TCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         const hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
