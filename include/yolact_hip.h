@@ -92,7 +92,9 @@ typedef struct yh_tuning {
                               * of the plan (captured with a second, one-node branch: DESIGN.md §8 on single-branch graphs) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0 keeps them on
                               * the main stream */
-    int32_t reserved[6];     /* -1 */
+    int32_t dsfuse;          /* a stage's projection shortcut evaluated inside the block's last 1x1 conv (two-source K, 1);
+                              * creation time only */
+    int32_t reserved[5];     /* -1 */
 } yh_tuning;
 
 typedef struct yh_config {
@@ -350,6 +352,13 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
                      const uint16_t* w, const float* bias, int32_t cout, int32_t kh, int32_t kw,
                      int32_t stride, int32_t pad, const uint16_t* residual, int32_t act,
                      uint16_t* y);
+/* The two-source 1x1 convolution (a bottleneck block's last conv and its projection shortcut as one accumulation):
+ * y[n][ho][wo][cout] = act(bias + sum_c w[o][c] x1[n][p][q][c] + sum_c w[o][c1 + c] x2[n][p*stride2][q*stride2][c]),
+ * x1: [n][ho][wo][c1], x2: [n][h2][w2][c2], w: [cout][c1 + c2] f16 bits; c1, c2 % 64 == 0, cout % 8 == 0; act 0 / 1 (relu).
+ * tune.op_tile selects the tile (those of the two-source form only), tune.op_kslices a split-K. */
+int yh_op_conv2d_dual_f16(yh_engine* h, const uint16_t* x1, int32_t n, int32_t ho, int32_t wo, int32_t c1,
+                          const uint16_t* x2, int32_t h2, int32_t w2, int32_t c2, int32_t stride2,
+                          const uint16_t* w, const float* bias, int32_t cout, int32_t act, uint16_t* y);
 /* Bilinear resize (align_corners = false) of an NHWC f16 tensor, optional accumulate into dst. */
 int yh_op_bilinear_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int32_t ww, int32_t c,
                        int32_t ho, int32_t wo, uint16_t* y);

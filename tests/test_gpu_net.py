@@ -223,6 +223,41 @@ def test_fpn_upsample_in_the_lateral_epilogue_is_bitwise_the_two_kernel_form(bui
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("S2,n,backbone,plan_cus", [(128, 2, 50, -1), (145, 1, 101, -1), (224, 3, 50, 4)])
+def test_projection_shortcut_inside_the_last_conv_matches_the_two_conv_form(built, oracle, S2, n, backbone, plan_cus):
+    """tune.dsfuse (default): a stage's first block accumulates its 1x1 projection shortcut inside its last 1x1 conv
+    (two-source K: ConvParams::x2) - the projected tensor "l<L>b0_d" is never written. The fused form skips ONE f16
+    rounding (of the projection, before the add), so the block outputs differ from the two-conv form by at most one f16
+    ulp of the sum and the stage outputs / heads by the usual f16 noise: asserted against the two-conv engine AND against
+    the oracle (which rounds the projection), both at the tolerance the forward test uses. plan_cus = 4 plans as for a
+    4-CU chip, which sends these small tensors down the batch-64 launch forms (streaming tile, 256x256 + tail)."""
+    import yolact_amd as ya
+    img = np.random.default_rng(S2 + 1).integers(0, 256, (n, S2, S2, 3), dtype=np.uint8)
+    res = []
+    for dsfuse in (1, 0):
+        eng = ya.Engine(input_size=S2, backbone=backbone, max_batch=n, use_graph=False, conf_thresh=THRESH, tune=dict(dsfuse=dsfuse, plan_cus=plan_cus))
+        blob = eng.generate_weights(1)
+        eng.load_weights(blob)
+        eng.set_input(img)
+        eng.evaluate()
+        names = [p["name"] for p in eng.profile(with_tail=False, reps=1)]
+        assert any(n_.endswith("b0_d") for n_ in names) == (dsfuse == 0)
+        assert len(names) == len(set(names))
+        res.append(([eng.tensor(t) for t in ("l1b0", "c2", "l2b0", "c3", "c4", "c5", "p3")], [eng.output(i) for i in range(4)]))
+        if dsfuse:
+            with pytest.raises(ya.YhError):
+                eng.tensor("l1b0_d")                    # fused away (debug_tensors = 1 keeps the two-conv form)
+        eng.close()
+    for a, b in zip(res[0][0], res[1][0]):              # named tensors: a few f16 ulps of the tensor's scale
+        assert np.abs(a - b).max() <= 0.01 * max(1.0, np.abs(b).max())
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.abs(a - b).max() <= 0.02 * max(1.0, np.abs(b).max())
+    net = oracle.Net(backbone, S2, 81, blob=blob)
+    want = net.forward(img, f16=True)
+    for i in range(4):
+        assert np.abs(res[0][1][i] - want[i]).max() <= 0.03 * max(1.0, np.abs(want[i]).max()), i
+
+
 def test_graph_replay_equals_eager(built, golden_dir):
     import yolact_amd as ya
     img = _frames(golden_dir)

@@ -229,6 +229,46 @@ def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     assert np.array_equal(y, oracle.conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1, f16=True))
 
 
+_DUAL_TILES = {"128x128": 0, "128x128_K1": 21, "128x128_S3": 7, "64x64_S3": 16, "128x128_M16": 12, "128x128_S3_M16": 13, "256x256_M16": 8}
+
+
+@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _DUAL_TILES] + [("128x128_S3", 2), ("128x128_S3", 3), ("64x64_S3", 2), ("64x64_S3", 5)])
+@pytest.mark.parametrize("stride2,c1,c2", [(1, 64, 64), (2, 128, 256), (2, 64, 192)])
+def test_dual_source_conv_exact_on_integers(eng, oracle, tile, kslices, stride2, c1, c2):
+    """The two-source 1x1 form (a bottleneck block's last conv + its projection shortcut as one accumulation over
+    [x1 | x2 at stride2]) on every tile it is instantiated for, split-K slices starting before, at and after the switch
+    of sources: equal, bit for bit, to the oracle's 1x1 conv of the channel-concatenated tensors. Ragged M (two images
+    straddling tiles), odd source size under stride 2 (the last source row / column is never read)."""
+    rng = np.random.default_rng(c1 + c2 + stride2)
+    n, ho, wo, cout = 2, 13, 11, 256
+    h2, w2 = (ho - 1) * stride2 + 1 + (stride2 - 1), (wo - 1) * stride2 + 1
+    x1 = rng.integers(-3, 4, (n, ho, wo, c1)).astype(np.float32)
+    x2 = rng.integers(-3, 4, (n, h2, w2, c2)).astype(np.float32)
+    wt = rng.integers(-2, 3, (cout, c1 + c2)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    env = {"op_tile": _DUAL_TILES[tile]}
+    if kslices: env["op_kslices"] = kslices
+    y = _forced(eng, env, lambda: eng.op_conv2d_dual(x1, x2, stride2, wt, b, act=1))
+    cat = np.concatenate([x1, x2[:, ::stride2, ::stride2][:, :ho, :wo]], axis=-1)
+    yo = oracle.conv2d(f16(cat), f16(wt.reshape(cout, 1, 1, c1 + c2)), b, 1, 0, None, 1, f16=True)
+    assert np.array_equal(y, yo), tile
+
+
+def test_dual_source_conv_vs_oracle_on_reals(eng, oracle):
+    """... and on real-valued data (the engine's shapes of layer 2, block 0, on a small map): within one f16 ulp of the
+    oracle's conv of the concatenated tensors (f32 accumulation on both sides, different summation order)."""
+    rng = np.random.default_rng(11)
+    n, ho, wo, c1, c2, cout = 2, 9, 9, 128, 256, 512
+    x1 = f16(rng.normal(0, 1, (n, ho, wo, c1)))
+    x2 = f16(rng.normal(0, 1, (n, 2 * ho, 2 * wo, c2)))
+    wt = f16(rng.normal(0, 1, (cout, c1 + c2)) / np.sqrt(c1 + c2))
+    b = rng.normal(0, 0.1, cout).astype(np.float32)
+    y = eng.op_conv2d_dual(x1, x2, 2, wt, b, act=1)
+    cat = np.concatenate([x1, x2[:, ::2, ::2]], axis=-1)
+    yo = oracle.conv2d(cat, wt.reshape(cout, 1, 1, c1 + c2), b, 1, 0, None, 1, f16=True)
+    assert np.all(np.abs(y - yo) <= 2.0 ** -10 * np.maximum(np.abs(yo), 1.0) + 1e-3)
+
+
 @pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))

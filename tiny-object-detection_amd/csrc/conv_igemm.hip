@@ -92,9 +92,13 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 //      lane); 16: v_mfma_f32_16x16x32_f16 (K = 32, 4 accumulators per lane: lane l holds output
 //      pixel l & 15 and channels 4 (l >> 4) .. + 3). Same FLOPs per cycle; on real data the chip
 //      holds a higher clock on the 16x16x32 shape (guide: DVFS give-back item 7).
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false>
+// DUAL: two-source 1x1 form (ConvParams::x2): after k-step k1steps - 1 the loader switches to the second tensor - its
+//      per-row source offsets are recomputed IN PLACE at the switch (no registers of their own while the accumulators
+//      are live) and the buffer descriptor is swapped; the weight panel simply continues along K.
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false, bool DUAL = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
+    static_assert(!DUAL || (!ML && !SMALLC && !FP8 && !RESUP), "two-source form: plain 1x1 convolutions");
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
     constexpr int TC = WTC / MT, TMT = WTM / MT;   // MFMA tiles per wave
@@ -165,8 +169,10 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             xbase[i] = 0;
         }
     }
-    const __amdgpu_buffer_rsrc_t xrsrc =
+    __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    unsigned x_zero_off = p.x_zero_off;
+    int wk_shift = 0;   // DUAL: K index at which the current source's channels start in the weight panel
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
     const unsigned wbase = (unsigned)(((ch_tile * TCH + rb) * p.ldw + lc * 8) * 2);
@@ -182,6 +188,24 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         kr = rs / p.S;
         ks = rs - kr * p.S;
     }
+    // DUAL: from k-step k1steps on, the rows come from the second tensor (1x1, no padding: a row is in the image or past M)
+    auto second_source = [&]() {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int m = m_tile * TM + rb + RSTEP * i;
+            if (m < p.M) {
+                const int n = m / PQ, rem = m - n * PQ, op = rem / p.Q, oq = rem - op * p.Q;
+                xbase[i] = (int)(n * p.x2_img_stride) + (op * p.W2 + oq) * p.stride2 * p.C2 + lc * 8;
+                xih[i] = 0;
+            }
+            xiw[i] = 0;
+        }
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, (int)p.x2_bytes, 0x00020000);
+        x_zero_off = p.x2_zero_off;
+        wk_shift = p.k1steps << 6;
+        kc = (kt_load - p.k1steps) << 6;
+    };
+    if (DUAL && kt_load >= p.k1steps) second_source();   // (a split-K slice that starts inside the second source)
 
     // One tile's DMA is NDMA instructions per thread (WL weight pieces, then XL activation pieces).
     // tile_begin fixes the tile's K position, tile_part issues piece d, tile_end advances K.
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             t_r = kr; t_s = ks; kc_cur = kc;
             t_off = (kr * p.W + ks) * p.C + kc;
             t_wk = (kr * p.S + ks) * p.C + kc;   // K index of this step in the [(r,s,c)] weight panel
+            if (DUAL) t_wk = wk_shift + kc;
         }
     };
     auto tile_part = [&](int buf, int d) {
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                                : ((unsigned)(xih[i] + t_r) < (unsigned)p.H && (unsigned)(xiw[i] + t_s) < (unsigned)p.W);
             // padded taps read the 16-byte zero block that ends every activation allocation
             const int toff = ML ? (t_r * xW[i] + t_s) * p.C + kc_cur : t_off;
-            const unsigned voff = ok ? (unsigned)(xbase[i] + toff) * 2u : p.x_zero_off;
+            const unsigned voff = ok ? (unsigned)(xbase[i] + toff) * 2u : x_zero_off;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, dstw + TCH * 128 + i * (RSTEP * 128), 16, (int)voff, 0, 0, 0);
         }
     };
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             // the 4 MiB L2, where tap-outer order streamed ~8 MB between two uses of a line.
             if (++ks == p.S) { ks = 0; if (++kr == p.R) { kr = 0; kc += 64; } }
         }
+        if (DUAL && kt_load == p.k1steps) second_source();
     };
     auto load_tile = [&](int buf) {
         tile_begin();
@@ -826,6 +852,28 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
             case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (p.x2) {   // two-source 1x1 form (a bottleneck block's last conv + its projection): the tiles dual_conv_tile() maps to
+        if (p.R != 1 || p.S != 1 || p.pad != 0 || p.stride != 1 || p.res_up || p.k1steps < 1 || p.k1steps >= p.ksteps || p.C2 % 64 != 0) return hipErrorInvalidValue;
+        if (p.k_slices > 1) {
+            const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
+            if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true, 32, false, false, false, true>), gk, dim3(256), 0, stream, p);
+            else if (tile == TILE_64x64_S3) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, true, 32, false, false, false, true>), gk, dim3(256), 0, stream, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
+        switch (tile) {
+            case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, false, false, false, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, false, false, true>), grid, dim3(512), 0, stream, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

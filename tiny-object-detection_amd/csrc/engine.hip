@@ -40,6 +40,7 @@ struct Panel {             // device-side repacked weights of one launched conv
     int cout = 0, coutPad = 0, Kpad = 0, cin_store = 0, k = 0;
     ConvTile tile = TILE_128x128;
     std::vector<int> src;  // canonical conv indices concatenated along cout
+    int kcat = -1;         // >= 0: this canonical conv's weights are appended ALONG K (two-source 1x1 form, ConvParams::x2); biases add
     // fp8 precision: the same weights as E4M3 codes, one scale per output channel
     bool fp8 = false;
     uint8_t* w8 = nullptr;     // [coutPad][Kpad] E4M3
@@ -68,6 +69,9 @@ struct Op {
     Buf in, out, res;
     bool has_res = false;
     bool res_up = false;   // the residual is the bilinear resize of the lower-resolution tensor `res` (ConvParams::res_up)
+    bool dual = false;     // two-source 1x1 form: K continues over `in2` read at `stride2` (ConvParams::x2)
+    Buf in2;
+    int stride2 = 1;
     int panel = -1;
     int stride = 1, pad = 0, act = 0, tanh_from = INT_MAX;
     int P = 0, Q = 0;      // output spatial
@@ -103,7 +107,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -114,7 +118,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
-    r.tailfork = d(t.tailfork, 1);
+    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1);
     return r;
 }
 
@@ -295,6 +299,17 @@ int add_panel(yh_engine* h, std::vector<int> src) {
     return (int)h->panels.size() - 1;
 }
 
+// A 1x1 conv and a second 1x1 conv with the same output channels as ONE panel along K (rows [W_a | W_b], bias a + b).
+int add_panel_kcat(yh_engine* h, int conv_a, int conv_b) {
+    const int id = add_panel(h, { conv_a });
+    Panel& p = h->panels[id];
+    p.kcat = conv_b;
+    p.Kpad += h->convs[conv_b].cin;
+    if (p.tile == TILE_128x128 && p.Kpad >= h->tune.bigk) p.tile = (p.cout % 256 == 0) ? TILE_256x256 : TILE_128x256;
+    p.coutPad = round_up(p.cout, conv_tile_ch(p.tile));
+    return id;
+}
+
 Op conv_op(yh_engine* h, const char* name, int panel, const Buf& in, const Buf& out, int stride, int pad,
            int act, const Buf* res) {
     Op o;
@@ -369,6 +384,10 @@ int build_graph_spec(yh_engine* h) {
     }
     Buf x = pool, cfeat[4];
     char nm[32];
+    // tune.dsfuse (default): a stage's first block evaluates its projection shortcut inside its last 1x1 conv (two-source
+    // form) - the projected tensor is never written or re-read; engines with debug_tensors = 1 keep the two convs so that
+    // "l<L>b0_d" can be read.
+    const bool dsfuse = h->tune.dsfuse && !h->cfg.debug_tensors;
     for (int L = 0; L < 4; ++L) {
         const int planes = 64 << L;
         for (int b = 0; b < blocks_of(h->cfg.backbone, L); ++b) {
@@ -383,6 +402,24 @@ int build_graph_spec(yh_engine* h) {
             h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), a, bt, stride, 1, 1, nullptr));
             const int ci3 = ci++;
             Buf resb = x;
+            if (b == 0 && dsfuse) {
+                // the block's last 1x1 conv and its 1x1 projection as one accumulation over [bt | x at `stride`] (ConvParams::x2)
+                snprintf(nm, sizeof nm, "l%db%d_d", L + 1, b);
+                h->fused_away.insert(nm);
+                const int cid = ci++;
+                const bool last = b == blocks_of(h->cfg.backbone, L) - 1;
+                if (last) snprintf(nm, sizeof nm, "c%d", L + 2);
+                else snprintf(nm, sizeof nm, "l%db%d", L + 1, b);
+                if ((rc = new_buf(h, nm, ho, ho, planes * 4, &y))) return rc;
+                Op o = conv_op(h, nm, add_panel_kcat(h, ci3, cid), bt, y, 1, 0, 1, nullptr);
+                o.dual = true; o.in2 = x; o.stride2 = stride;
+                o.flops_per_img = 2.0 * o.P * o.Q * (planes * 4.0) * (planes + x.c);
+                o.bytes_per_img = 2.0 * ((double)o.P * o.Q * (planes + x.c) + (double)o.P * o.Q * planes * 4);
+                o.bytes_fixed = 2.0 * planes * 4.0 * (planes + x.c);
+                h->ops.push_back(o);
+                x = y;
+                continue;
+            }
             if (b == 0) {
                 snprintf(nm, sizeof nm, "l%db%d_d", L + 1, b);
                 if ((rc = new_buf(h, nm, ho, ho, planes * 4, &dn))) return rc;
@@ -549,6 +586,7 @@ void plan_fp8(yh_engine* h) {
             if (c.kind == OP_PRE) continue;
             if (overlap(w, range(c.in))) { if (c.fp8) need_q = true; else need_f16 = true; }
             if (c.has_res && c.kind == OP_CONV && overlap(w, range(c.res))) need_f16 = true;
+            if (c.dual && overlap(w, range(c.in2))) need_f16 = true;
         }
         if (overlap(w, range(h->heads)) || overlap(w, range(h->proto))) need_f16 = true;   // engine outputs, read by the tail
         if (!need_q && !need_f16) need_f16 = true;
@@ -561,6 +599,7 @@ void plan_fp8(yh_engine* h) {
         if (o.kind == OP_BILINEAR) { o.bytes_per_img = 2.0 * o.in.c * (double)o.in.h * o.in.w + out_b * o.in.c * (double)o.out.h * o.out.w; continue; }
         const Panel& pn = h->panels[o.panel];
         const ConvDesc& d0 = h->convs[pn.src[0]];
+        if (o.dual) continue;   // (f16 on both sides: the figures set at construction stand)
         const double K = (double)pn.k * pn.k * d0.cin, in_elems = o.nlev ? (double)h->cells * d0.cin : (double)o.in.h * o.in.w * d0.cin;
         o.bytes_per_img = (o.fp8 ? 1.0 : 2.0) * in_elems + (double)o.P * o.Q * pn.cout * (out_b + (o.has_res ? 2.0 : 0.0));
         o.bytes_fixed = (o.fp8 ? 1.0 : 2.0) * pn.cout * K;
@@ -754,6 +793,17 @@ hipError_t launch_conv_planned(const Tune& tu, const ConvParams& p, ConvTile til
     return hipSuccess;
 }
 
+// The tiles launch_conv instantiates for the two-source form; the others map to their nearest relative.
+ConvTile dual_conv_tile(ConvTile t) {
+    switch (t) {
+        case TILE_128x128: case TILE_128x128_K1: case TILE_128x128_S3: case TILE_64x64_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x256_M16: return t;
+        case TILE_128x128_S4: return TILE_128x128_S3;
+        case TILE_64x64_S4: return TILE_64x64_S3;
+        case TILE_256x256: return TILE_256x256_M16;
+        default: return TILE_128x128;
+    }
+}
+
 int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile* tile_out = nullptr) {
     const Panel& pn = h->panels[o.panel];
     ConvParams p;
@@ -776,6 +826,13 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     const long long pq = (long long)o.P * o.Q;
     p.y_dense = (o.out.img_stride == pq * o.out.c) && (!o.has_res || o.res_up || o.res.img_stride == pq * o.res.c);
     if (o.res_up) { p.res_up = 1; p.res_h = o.res.h; p.res_w = o.res.w; }
+    if (o.dual) {
+        const long long z2 = (const char*)o.in2.zero - (const char*)o.in2.d;
+        if (z2 < 0 || z2 >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+        p.x2 = o.in2.d; p.x2_img_stride = o.in2.img_stride; p.x2_zero_off = (unsigned)z2; p.x2_bytes = (unsigned)z2 + 16u;
+        p.W2 = o.in2.w; p.C2 = o.in2.c; p.stride2 = o.stride2; p.k1steps = pn.cin_store / 64;
+        if (h->tune.ablate & 1) { p.x2_bytes = 0; }
+    }
     p.act = o.act; p.tanh_from = o.tanh_from;
     p.nlev = o.nlev;
     for (int l = 0; l < 5; ++l) { p.lev_start[l] = o.lev_start[l]; p.lev_h[l] = o.lev_h[l]; p.lev_w[l] = o.lev_w[l]; }
@@ -783,6 +840,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     if (h->tune.ablate & 1) { p.x_bytes = 0; }
     if (h->tune.ablate & 2) { p.w_bytes = 0; }
     ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
+    if (o.dual) tile = dual_conv_tile(tile);
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
         p.y = o.write_f16 ? o.out.d : nullptr;
@@ -1024,6 +1082,17 @@ int upload_panels(yh_engine* h, const uint8_t* blob) {
             memcpy(bias.data() + row0, blob + d.blob_b_off, (size_t)d.cout * 4);
             row0 += d.cout;
         }
+        if (p.kcat >= 0) {   // two-source form: the second conv's rows continue along K, its bias adds (one f32 addition)
+            const ConvDesc& d = h->convs[p.kcat];
+            const size_t K1 = (size_t)p.Kpad - d.cin;
+            const uint16_t* src = (const uint16_t*)(blob + d.blob_w_off);
+            const float* b2 = (const float*)(blob + d.blob_b_off);
+            for (int o = 0; o < d.cout; ++o) {
+                memcpy(w.data() + (size_t)o * p.Kpad + K1, src + (size_t)o * d.cin, (size_t)d.cin * 2);
+                float bb; memcpy(&bb, b2 + o, 4);
+                bias[o] = bias[o] + bb;
+            }
+        }
         HIPCHK(h, hipMemcpy(p.w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(p.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (p.fp8) {
@@ -1205,7 +1274,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse;
     return YH_OK;
 }
 
@@ -1716,11 +1785,11 @@ const uint32_t* yh_classify_device_frame(const yh_engine* h) { return h ? h->fra
 
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;
+    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
-    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
-        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     const Buf& b = it->second;
     const int n = h->cur_n;
     const size_t per = (size_t)b.h * b.w * b.c;
@@ -1744,12 +1813,12 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
 
 int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;
+    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
     if (frame < 0 || frame >= h->cur_n) return h->fail(YH_EINVAL, "frame out of range");
-    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
-        return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     const Buf& b = it->second;
     const size_t per = (size_t)b.h * b.w * b.c;
     dims[0] = 1; dims[1] = b.h; dims[2] = b.w; dims[3] = b.c;
@@ -1949,6 +2018,65 @@ int yh_op_conv2d_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh, int
                      const float* bias, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                      const uint16_t* residual, int32_t act, uint16_t* y) {
     return op_conv2d_impl(h, x, n, hh, ww, cin, w, bias, cout, kh, kw, stride, pad, residual, act, y, nullptr, 0);
+}
+
+int yh_op_conv2d_dual_f16(yh_engine* h, const uint16_t* x1, int32_t n, int32_t ho, int32_t wo, int32_t c1,
+                          const uint16_t* x2, int32_t h2, int32_t w2, int32_t c2, int32_t stride2,
+                          const uint16_t* w, const float* bias, int32_t cout, int32_t act, uint16_t* y) {
+    if (!h || !x1 || !x2 || !w || !bias || !y) return YH_EINVAL;
+    if (n < 1 || ho < 1 || wo < 1 || c1 < 64 || c1 % 64 != 0 || c2 < 64 || c2 % 64 != 0 || stride2 < 1 || cout < 1 || cout % 8 != 0 || act < 0 || act > 1 ||
+        (ho - 1) * stride2 >= h2 || (wo - 1) * stride2 >= w2)
+        return h->fail(YH_EINVAL, "dual conv op: need c1, c2 % 64 == 0, cout % 8 == 0 and x2 covering the strided output grid");
+    HIPCHK(h, hipSetDevice(h->dev));
+    ConvTile tile = TILE_128x128;
+    if (h->tune.op_tile >= 0) tile = (ConvTile)h->tune.op_tile;
+    if (conv_tile_ch(tile) == 0 || dual_conv_tile(tile) != tile) return h->fail(YH_EINVAL, "dual conv op: tune.op_tile is not a tile of the two-source form");
+    const int K = c1 + c2, coutPad = round_up(cout, conv_tile_ch(tile));
+    const size_t M = (size_t)n * ho * wo, n1 = M * c1, n2 = (size_t)n * h2 * w2 * c2;
+    std::vector<uint16_t> wp((size_t)coutPad * K, 0);
+    memcpy(wp.data(), w, (size_t)cout * K * 2);
+    std::vector<float> bp(coutPad, 0.0f);
+    memcpy(bp.data(), bias, (size_t)cout * 4);
+    void *d1 = nullptr, *d2 = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr;
+    hipError_t e = hipMalloc(&d1, n1 * 2 + 64);
+    if (e == hipSuccess) e = hipMemset(d1, 0, n1 * 2 + 64);
+    if (e == hipSuccess) e = hipMalloc(&d2, n2 * 2 + 64);
+    if (e == hipSuccess) e = hipMemset(d2, 0, n2 * 2 + 64);
+    if (e == hipSuccess) e = hipMalloc(&dw, wp.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&db, bp.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&dy, M * cout * 2);
+    if (e == hipSuccess) e = hipMemcpy(d1, x1, n1 * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d2, x2, n2 * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dw, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dy, 0xFF, M * cout * 2);
+    if (e == hipSuccess) {
+        ConvParams p;
+        memset(&p, 0, sizeof p);
+        p.x = (const half_t*)d1; p.w = (const half_t*)dw; p.bias = (const float*)db; p.y = (half_t*)dy;
+        p.x_img_stride = (long long)ho * wo * c1; p.y_img_stride = (long long)ho * wo * cout;
+        p.x_zero_off = (unsigned)((n1 * 2 + 15) & ~(size_t)15); p.x_bytes = p.x_zero_off + 16u;
+        p.x2 = (const half_t*)d2; p.x2_img_stride = (long long)h2 * w2 * c2;
+        p.x2_zero_off = (unsigned)((n2 * 2 + 15) & ~(size_t)15); p.x2_bytes = p.x2_zero_off + 16u;
+        p.W2 = w2; p.C2 = c2; p.stride2 = stride2; p.k1steps = c1 / 64;
+        p.w_bytes = (unsigned)(wp.size() * 2);
+        p.N = n; p.H = ho; p.W = wo; p.C = c1; p.P = ho; p.Q = wo; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+        p.M = (int)M; p.cout8 = cout; p.ldw = K; p.ksteps = K / 64; p.ldy = cout; p.y_dense = 1;
+        p.act = act; p.tanh_from = INT_MAX; p.n_ch_tiles = coutPad / conv_tile_ch(tile); p.k_slices = 1;
+        const int ksl = h->tune.op_kslices;   // test hook: a forced split-K
+        if (ksl > 1 && ksl <= p.ksteps && (size_t)ksl * M * coutPad * 4 <= yh_engine::kSplitKBytes && (tile == TILE_128x128_S3 || tile == TILE_64x64_S3)) {
+            p.ksteps_per_slice = (p.ksteps + ksl - 1) / ksl;
+            p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+            p.partial_ld = coutPad;
+            p.partial = h->splitk_ws;
+        }
+        e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(y, dy, M * cout * 2, hipMemcpyDeviceToHost);
+    hipFree(d1); hipFree(d2); hipFree(dw); hipFree(db); hipFree(dy);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("dual conv op: ") + hipGetErrorString(e));
+    return YH_OK;
 }
 
 int yh_op_conv2d_levels_f16(yh_engine* h, const uint16_t* x, int32_t n, const int32_t* level_sizes, int32_t nlev, int32_t cin,

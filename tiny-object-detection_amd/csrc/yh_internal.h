@@ -49,6 +49,14 @@ struct ConvParams {
     // e4m3((float)(f16 result) * y8_inv_scale), round to nearest even, saturating. y may then be nullptr.
     uint8_t* y8;
     float y8_inv_scale;
+    // two-source form (x2 != nullptr; 1x1 convolutions only): K is the concatenation of x's C channels (k-steps
+    // 0 .. k1steps-1) and of C2 channels of a SECOND tensor x2 [n][H2][W2][C2] read at stride2 (output pixel (p, q) <-
+    // x2 pixel (p*stride2, q*stride2)); the weight panel holds [W1 row | W2 row] along K. A bottleneck block's last 1x1
+    // conv and its 1x1 downsample projection as ONE accumulation: the projection is never written or re-read.
+    const half_t* x2;
+    long long x2_img_stride;
+    unsigned x2_bytes, x2_zero_off;
+    int W2, C2, stride2, k1steps;
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64

@@ -22,11 +22,11 @@ PRECISION_F16, PRECISION_FP8 = 0, 1
 # yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
 TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
                  "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
-                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork")
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse")
 
 
 class Tuning(C.Structure):
-    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 6)]
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 5)]
 
     @classmethod
     def of(cls, **kw):
@@ -134,6 +134,7 @@ SYMBOLS = [
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_quantize_e4m3", _i, [_vp, _vp, _sz, C.c_float, _vp]),
     ("yh_op_conv2d_fp8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    ("yh_op_conv2d_dual_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     ("yh_op_conv2d_levels_f16", _i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     ("yh_op_conv2d_f16", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     ("yh_op_bilinear_f16", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -438,6 +439,18 @@ class Engine:
         y = np.zeros((n, ho, wo, c), np.uint16)
         self._chk(self.L.yh_op_maxpool3x3s2_f16(self.h, _p(xb), n, hh, ww, c, _p(y)))
         return _bits_f32(y, y.shape)
+
+    def op_conv2d_dual(self, x1, x2, stride2, w, bias, act=0):
+        """The two-source 1x1 conv: x1 [n][ho][wo][c1], x2 [n][h2][w2][c2] read at stride2, w [cout][c1 + c2] -> [n][ho][wo][cout] f32."""
+        n, ho, wo, c1 = x1.shape
+        _, h2, w2, c2 = x2.shape
+        cout = w.shape[0]
+        assert w.shape[1] == c1 + c2
+        x1b, x2b, wb = _f16_bits(x1), _f16_bits(x2), _f16_bits(w)
+        bias = np.ascontiguousarray(bias, np.float32)
+        y = np.zeros((n, ho, wo, cout), np.uint16)
+        self._chk(self.L.yh_op_conv2d_dual_f16(self.h, _p(x1b), n, ho, wo, c1, _p(x2b), h2, w2, c2, stride2, _p(wb), _p(bias), cout, act, _p(y)))
+        return y.view(np.float16).astype(np.float32)
 
     def op_conv2d_levels(self, x, level_sizes, w, bias, act=0):
         """x [n][cells][cin] with cells = sum(s*s for s in level_sizes); w [cout][k][k][cin] -> [n][cells][cout] f32."""
