@@ -71,7 +71,7 @@ typedef struct yh_tuning {
     int32_t tailsplit;       /* two-phase launches against wave quantisation (1) */
     int32_t chsplit;         /* 256 + 128 channel split of the 384-channel head (1) */
     int32_t k1tile;          /* single-stage streaming tiles for HBM-bound layers: 0 off, 1..3 (3) */
-    int32_t k1_maxk;         /* ... for 1x1 layers with K <= this (512) */
+    int32_t k1_maxk;         /* ... for 1x1 layers with K <= this (1024) */
     int32_t splitk_minsteps; /* K-steps from which few-tile launches split K (12) */
     int32_t t64;             /* 64x64 tiles for latency-bound launches: 0 off, 1 never split K, 2 split K (2) */
     int32_t t64_maxb;        /* ... when at most this many 128x128 tiles (256) */
@@ -94,7 +94,9 @@ typedef struct yh_tuning {
                               * the main stream */
     int32_t dsfuse;          /* a stage's projection shortcut evaluated inside the block's last 1x1 conv (two-source K, 1);
                               * creation time only */
-    int32_t reserved[5];     /* -1 */
+    int32_t headfork_maxb;   /* batches up to this size run the prediction head (and the tail's K1-K3) on the second stream
+                              * beside the protonet (default: every batch size); 0: never (the tail's K1-K3 alone fork) */
+    int32_t reserved[4];     /* -1 */
 } yh_tuning;
 
 typedef struct yh_config {

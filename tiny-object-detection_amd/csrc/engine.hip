@@ -107,18 +107,18 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
     Tune r;
     r.plan_cus = t.plan_cus > 0 ? t.plan_cus : device_cus;
     r.mfma16 = d(t.mfma16, 1); r.t128x256_m16 = d(t.t128x256_m16, 1); r.small16 = d(t.small16, 0); r.bigk = d(t.bigk, 256);
-    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 3); r.k1_maxk = d(t.k1_maxk, 512);
+    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 3); r.k1_maxk = d(t.k1_maxk, 1024);
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
-    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1);
+    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20);
     return r;
 }
 
@@ -186,6 +186,8 @@ struct yh_engine {
     int last_conv_launches = 0;   // yh_debug_last_conv_launches
     bool stem_fused = false, pre_fused = false;
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
+    int head_fork_op = 0;   // ops[head_fork_op .. tail_fork_op) are the shared prediction head; the protonet does not read them
+    float* splitk_ws_side = nullptr;   // split-K workspace of convolutions launched on the side stream
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
 
@@ -517,6 +519,7 @@ int build_graph_spec(yh_engine* h) {
         return o;
     };
     for (int l = 0; l < 5; ++l) { snprintf(nm, sizeof nm, "head_t%d", l); h->named[nm] = level(h->pyr_t, l); }
+    h->head_fork_op = (int)h->ops.size();
     if (headmerge) {
         h->ops.push_back(merged("head_t", trunk_panel, h->pyr, h->pyr_t, 1));
         Op o = merged("head_out", out_panel, h->pyr_t, h->heads, 0);
@@ -886,8 +889,10 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     return YH_OK;
 }
 
-int launch_op(yh_engine* h, const Op& o, int n) {
+// side: the op runs on the side stream (with that stream's split-K workspace) - convolutions only
+int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
     hipError_t e = hipSuccess;
+    if (side && o.kind != OP_CONV) return h->fail(YH_EINVAL, "only convolutions fork onto the side stream");
     switch (o.kind) {
         case OP_PRE:
             e = launch_preprocess(h->in_u8, h->in_f16.d, n, h->S, h->in_hp, h->in_hp, h->stream);
@@ -897,7 +902,8 @@ int launch_op(yh_engine* h, const Op& o, int n) {
             ConvTile tile;
             int rc = fill_conv_params(h, o, n, &p, &tile);
             if (rc) return rc;
-            e = launch_conv_planned(h->tune, p, tile, h->panels[o.panel].coutPad, h->stream);
+            if (side && p.partial) p.partial = h->splitk_ws_side;
+            e = launch_conv_planned(h->tune, p, tile, h->panels[o.panel].coutPad, side ? h->side : h->stream);
             break;
         }
         case OP_POOL:
@@ -938,9 +944,16 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     // engine's graphs had been destroyed) ended in a GPU memory access fault on it with kernels and arguments that are
     // identical to the forked form's (profiles/r02_graph_replay_under_rocprofv3.md). Every capture that has no fork of its
     // own therefore gets a second branch - a 4-byte memset captured on the side stream - and replays node by node.
+    //
+    // tune.headfork_maxb (default: every batch size) forks earlier: the whole prediction head (two convolutions over the
+    // pyramid) and then the tail's K1-K3 run on the side stream beside the protonet's six convolutions, which need only
+    // P3. At small batches neither chain fills the chip (75-300 workgroups per launch at batch 1); at batch 64 each chain's
+    // launches fill the other's last, partly empty rounds. Measured against the tail-only fork on one box: batch 1 0.783 ->
+    // 0.756 ms, 4 1.423 -> 1.320, 8 2.084 -> 1.983, 16 3.346 -> 3.295, 64 10.47 -> 10.31. Same kernels, same bits.
     bool tail_forked = false;
     const bool fork = h->tune.tailfork != 0;
-    const bool dummy_branch = h->capturing && !(with_tail && fork);
+    const bool headfork = h->tune.headfork_maxb > 0 && n <= h->tune.headfork_maxb && h->head_fork_op < h->tail_fork_op;
+    const bool dummy_branch = h->capturing && !(with_tail && fork) && !headfork;
     if (dummy_branch) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -948,7 +961,23 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
         HIPCHK(h, hipEventRecord(h->ev_join, h->side));
     }
     for (size_t i = 0; i < h->ops.size(); ++i) {
-        if (with_tail && fork && (int)i == h->tail_fork_op) {
+        if (headfork && (int)i == h->head_fork_op) {
+            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            for (; (int)i < h->tail_fork_op; ++i) {
+                const int rc = launch_op(h, h->ops[i], n, true);
+                if (rc) return rc;
+            }
+            if (with_tail) {
+                h->det.n = n;
+                for (int st = 0; st < 4; ++st)
+                    if (launch_detect_stage(h->det, st, h->side) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
+                tail_forked = true;
+            }
+            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+            if (i == h->ops.size()) break;
+        }
+        if (!headfork && with_tail && fork && (int)i == h->tail_fork_op) {
             h->det.n = n;
             HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -969,7 +998,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
         } else e = launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
     }
-    if (dummy_branch) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    if (dummy_branch || (headfork && !tail_forked)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return YH_OK;
 }
 
@@ -1220,6 +1249,8 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
         void* q = nullptr;
         if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
         h->splitk_ws = (float*)q;
+        if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
+        h->splitk_ws_side = (float*)q;
     }
     e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
@@ -1274,7 +1305,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb;
     return YH_OK;
 }
 
