@@ -69,6 +69,7 @@ struct Op {
     Buf in, out, res;
     bool has_res = false;
     bool res_up = false;   // the residual is the bilinear resize of the lower-resolution tensor `res` (ConvParams::res_up)
+    bool side = false;     // may run on the second stream: nothing on the main stream reads its output before the step's join
     bool dual = false;     // two-source 1x1 form: K continues over `in2` read at `stride2` (ConvParams::x2)
     Buf in2;
     int stride2 = 1;
@@ -129,6 +130,7 @@ struct yh_engine {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;   // the detection tail's K1-K3 run here underneath the protonet
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_forks[4] = { nullptr, nullptr, nullptr, nullptr };   // one per fork point of a step (enqueue_all)
     std::string err;
 
     int S = 0, C = 0, ldh = 0;
@@ -484,14 +486,23 @@ int build_graph_spec(yh_engine* h) {
         o.bytes_per_img = 2.0 * ((double)feat.h * feat.w * feat.c + (double)lat.h * lat.w * lat.c + (double)lower.h * lower.w * lower.c);
         h->ops.push_back(o);
     };
+    // Canonical conv order (the weight blob's): lat5 lat4 lat3 p5 p4 p3 p6 p7. Launch order: each smoothing / downsampling
+    // conv right after the lateral it needs, tagged `side` - only the prediction head reads P4..P7, so they run on the
+    // second stream beside the top-down chain lat4 -> lat3 -> p3 (enqueue_all).
+    const int c_lat5 = ci, c_lat4 = ci + 1, c_lat3 = ci + 2, c_p5 = ci + 3, c_p4 = ci + 4, c_p3 = ci + 5, c_p6 = ci + 6, c_p7 = ci + 7;
+    auto side_op = [&](Op o) { o.side = true; h->ops.push_back(o); };
+    ci = c_lat5;
     h->ops.push_back(conv_op(h, "lat5", add_panel(h, { ci++ }), cfeat[3], lat5, 1, 0, 0, nullptr));
+    side_op(conv_op(h, "p5", add_panel(h, { c_p5 }), lat5, level(h->pyr, 2), 1, 1, 1, nullptr));
+    side_op(conv_op(h, "p6", add_panel(h, { c_p6 }), level(h->pyr, 2), level(h->pyr, 3), 2, 1, 0, nullptr));
+    side_op(conv_op(h, "p7", add_panel(h, { c_p7 }), level(h->pyr, 3), level(h->pyr, 4), 2, 1, 0, nullptr));
+    if (ci != c_lat4) return h->fail(YH_EINVAL, "conv cursor");
     lateral("lat4", cfeat[2], lat4, "up5", lat5, up5);
+    side_op(conv_op(h, "p4", add_panel(h, { c_p4 }), lat4, level(h->pyr, 1), 1, 1, 1, nullptr));
+    if (ci != c_lat3) return h->fail(YH_EINVAL, "conv cursor");
     lateral("lat3", cfeat[1], lat3, "up4", lat4, up4);
-    h->ops.push_back(conv_op(h, "p5", add_panel(h, { ci++ }), lat5, level(h->pyr, 2), 1, 1, 1, nullptr));
-    h->ops.push_back(conv_op(h, "p4", add_panel(h, { ci++ }), lat4, level(h->pyr, 1), 1, 1, 1, nullptr));
-    h->ops.push_back(conv_op(h, "p3", add_panel(h, { ci++ }), lat3, level(h->pyr, 0), 1, 1, 1, nullptr));
-    h->ops.push_back(conv_op(h, "p6", add_panel(h, { ci++ }), level(h->pyr, 2), level(h->pyr, 3), 2, 1, 0, nullptr));
-    h->ops.push_back(conv_op(h, "p7", add_panel(h, { ci++ }), level(h->pyr, 3), level(h->pyr, 4), 2, 1, 0, nullptr));
+    h->ops.push_back(conv_op(h, "p3", add_panel(h, { c_p3 }), lat3, level(h->pyr, 0), 1, 1, 1, nullptr));
+    ci = c_p7 + 1;
     for (int l = 0; l < 5; ++l) { snprintf(nm, sizeof nm, "p%d", l + 3); h->named[nm] = level(h->pyr, l); }
     // ---- shared prediction head: trunk, then box|conf|mask fused along cout
     const int ci_proto = ci;          // proto0..3 + proto out occupy the next five canonical convs
@@ -537,6 +548,7 @@ int build_graph_spec(yh_engine* h) {
     // ---- protonet (listed after the heads so the detection tail's K1-K3, which need only the head
     // rows, can run on a side stream underneath it; canonical conv indices are unchanged)
     h->tail_fork_op = (int)h->ops.size();
+    for (int i = h->head_fork_op; i < h->tail_fork_op; ++i) h->ops[i].side = true;
     ci = ci_proto;
     Buf q = level(h->pyr, 0);
     for (int i = 0; i < 3; ++i) {
@@ -952,7 +964,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     // 0.756 ms, 4 1.423 -> 1.320, 8 2.084 -> 1.983, 16 3.346 -> 3.295, 64 10.47 -> 10.31. Same kernels, same bits.
     bool tail_forked = false;
     const bool fork = h->tune.tailfork != 0;
-    const bool headfork = h->tune.headfork_maxb > 0 && n <= h->tune.headfork_maxb && h->head_fork_op < h->tail_fork_op;
+    const bool headfork = h->tune.headfork_maxb > 0 && n <= h->tune.headfork_maxb;
     const bool dummy_branch = h->capturing && !(with_tail && fork) && !headfork;
     if (dummy_branch) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
@@ -960,45 +972,46 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
         HIPCHK(h, hipMemsetAsync(h->side_word, 0, 4, h->side));
         HIPCHK(h, hipEventRecord(h->ev_join, h->side));
     }
+    // Ops tagged `side` (the FPN's P4..P7 convolutions and the prediction head: nothing on the main stream reads them before
+    // the join) run on the second stream when headfork is on. Every run of side ops starts with a fork - the side stream
+    // waits for everything the main stream has been given so far (its inputs are among that) - and the side stream is in
+    // order itself; the main stream waits for the side stream once, before the mask kernel (or at the end of the step).
+    int n_forks = 0;
+    bool prev_side = false, used_side = false;
+    auto fork_to_side = [&]() -> int {
+        hipEvent_t ev = h->ev_forks[n_forks++ & 3];
+        HIPCHK(h, hipEventRecord(ev, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side, ev, 0));
+        used_side = true;
+        return YH_OK;
+    };
     for (size_t i = 0; i < h->ops.size(); ++i) {
-        if (headfork && (int)i == h->head_fork_op) {
-            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            for (; (int)i < h->tail_fork_op; ++i) {
-                const int rc = launch_op(h, h->ops[i], n, true);
-                if (rc) return rc;
-            }
-            if (with_tail) {
-                h->det.n = n;
-                for (int st = 0; st < 4; ++st)
-                    if (launch_detect_stage(h->det, st, h->side) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
-                tail_forked = true;
-            }
-            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
-            if (i == h->ops.size()) break;
-        }
-        if (!headfork && with_tail && fork && (int)i == h->tail_fork_op) {
+        if (with_tail && (fork || headfork) && (int)i == h->tail_fork_op) {
+            // the tail's K1-K3 follow the head on the side stream (or fork there now, behind a head that ran on the main stream)
+            if (!prev_side) { const int rc = fork_to_side(); if (rc) return rc; }
             h->det.n = n;
-            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
             for (int st = 0; st < 4; ++st)
                 if (launch_detect_stage(h->det, st, h->side) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
-            HIPCHK(h, hipEventRecord(h->ev_join, h->side));
             tail_forked = true;
+            prev_side = false;
         }
-        int rc = launch_op(h, h->ops[i], n);
+        const bool side = headfork && h->ops[i].side;
+        if (side && !prev_side) { const int rc = fork_to_side(); if (rc) return rc; }
+        const int rc = launch_op(h, h->ops[i], n, side);
         if (rc) return rc;
+        prev_side = side;
+    }
+    if (used_side) {
+        HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
     if (with_tail) {
         h->det.n = n;
-        hipError_t e;
-        if (tail_forked) {
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            e = launch_detect_stage(h->det, 4, h->stream);   // masks: need the prototypes too
-        } else e = launch_detect(h->det, h->stream);
+        const hipError_t e = tail_forked ? launch_detect_stage(h->det, 4, h->stream)   // masks: need the prototypes too
+                                         : launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
     }
-    if (dummy_branch || (headfork && !tail_forked)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    if (dummy_branch) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return YH_OK;
 }
 
@@ -1227,6 +1240,7 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    for (hipEvent_t& ev : h->ev_forks) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("device setup: ") + hipGetErrorString(e); return bail(YH_EHIP); }
     build_conv_table(h);
     int rc = build_graph_spec(h);
@@ -1273,6 +1287,7 @@ void yh_destroy(yh_engine* h) {
     if (h->diverged_dev) hipFree(h->diverged_dev);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    for (hipEvent_t ev : h->ev_forks) if (ev) hipEventDestroy(ev);
     for (int k = 0; k < 2; ++k) { if (h->stage_ev[k]) hipEventDestroy(h->stage_ev[k]); if (h->stage[k]) hipHostFree(h->stage[k]); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
