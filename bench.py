@@ -228,14 +228,19 @@ def host_to_detections_latency(eng, host_frames, reps=100):
     return dict(n=reps, median_ms=round(float(np.median(t)), 4), p99_ms=round(float(np.percentile(t, 99)), 4))
 
 
-def accuracy_vs_oracle(eng_out, orc_out):
+def accuracy_vs_oracle(eng_out, orc_out, cut_band=0.02):
     """Engine vs CPU oracle on the same frame and weights (the restated acceptance target of SURVEY.md §8c; NOT
     parity with CPU tflite). Order-insensitive and over ALL detections of both sides:
       mask_iou_all  per class, the union of the engine's masks against the union of the oracle's masks,
                     intersections and unions summed over the classes either side detected - a detection only one
                     side has counts against it with every pixel of its mask;
       matched / unmatched_*  detections paired by (class, prior);
-      mask_iou_matched  the survivor statistic round 1 reported (matched pairs only), kept for comparison."""
+      mask_iou_matched  the survivor statistic round 1 reported (matched pairs only), kept for comparison;
+      mask_iou_above_cut / unmatched_above_cut  the same union figure and count WITHOUT the detections that sit on the
+                    top-k cut: when both lists are full (max_dets each), the last places go to whichever candidates are
+                    ahead in the 4th decimal of the score, and f16 summation order decides that - detections of either
+                    side whose score is within cut_band (2 %) of the lowest score kept are left out of this pair of figures
+                    (and only of this pair)."""
     import numpy as np
     (ed, em), (od, om) = eng_out, orc_out
     ek = {(d["class_id"], d["prior"]): i for i, d in enumerate(ed)}
@@ -247,21 +252,34 @@ def accuracy_vs_oracle(eng_out, orc_out):
         matched += 1
         a, b = em[i] > 0, om[j] > 0
         inter += int(np.logical_and(a, b).sum()); union += int(np.logical_or(a, b).sum())
-    ia = ua = 0
     shape = em.shape[1:] if len(ed) else om.shape[1:]
-    for c in sorted({d["class_id"] for d in ed} | {d["class_id"] for d in od}):
-        ue, uo = np.zeros(shape, bool), np.zeros(shape, bool)
-        for i, d in enumerate(ed):
-            if d["class_id"] == c:
-                ue |= em[i] > 0
-        for j, d in enumerate(od):
-            if d["class_id"] == c:
-                uo |= om[j] > 0
-        ia += int((ue & uo).sum()); ua += int((ue | uo).sum())
-    return dict(oracle_dets=len(od), engine_dets=len(ed), matched_class_and_prior=matched,
-                unmatched_oracle=len(od) - matched, unmatched_engine=len(ed) - matched,
-                mask_iou_all=round(ia / ua, 5) if ua else None,
-                mask_iou_matched=round(inter / union, 5) if union else None)
+
+    def union_iou(keep_e, keep_o):
+        ia = ua = 0
+        for c in sorted({ed[i]["class_id"] for i in keep_e} | {od[j]["class_id"] for j in keep_o}):
+            ue, uo = np.zeros(shape, bool), np.zeros(shape, bool)
+            for i in keep_e:
+                if ed[i]["class_id"] == c:
+                    ue |= em[i] > 0
+            for j in keep_o:
+                if od[j]["class_id"] == c:
+                    uo |= om[j] > 0
+            ia += int((ue & uo).sum()); ua += int((ue | uo).sum())
+        return round(ia / ua, 5) if ua else None
+    all_e, all_o = list(range(len(ed))), list(range(len(od)))
+    out = dict(oracle_dets=len(od), engine_dets=len(ed), matched_class_and_prior=matched,
+               unmatched_oracle=len(od) - matched, unmatched_engine=len(ed) - matched,
+               mask_iou_all=union_iou(all_e, all_o),
+               mask_iou_matched=round(inter / union, 5) if union else None)
+    if len(ed) and len(ed) == len(od) and all("score" in d for d in ed + od):   # both lists full: there is a cut
+        cut = max(min(d["score"] for d in ed), min(d["score"] for d in od)) * (1.0 + cut_band)
+        key_e, key_o = [(d["class_id"], d["prior"]) for d in ed], [(d["class_id"], d["prior"]) for d in od]
+        above = {key_e[i] for i in all_e if ed[i]["score"] > cut} | {key_o[j] for j in all_o if od[j]["score"] > cut}
+        # (a detection above the band on one side and inside it on the other stays in on both sides)
+        ke, ko = [i for i in all_e if key_e[i] in above], [j for j in all_o if key_o[j] in above]
+        out.update(mask_iou_above_cut=union_iou(ke, ko), unmatched_above_cut=len(above - set(key_e)) + len(above - set(key_o)),
+                   dets_above_cut=len(above))
+    return out
 
 
 def parse_blob(blob):
@@ -333,7 +351,19 @@ def torch_cpu_forward(torch, convs, frames_u8, backbone=50):
     return torch.cat(loc, 1), torch.cat(cf, 1), torch.cat(mk, 1), proto.permute(0, 2, 3, 1).contiguous()
 
 
-def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, backbone=50, fp8_layers=None):
+def acceptance_frame(size):
+    """The reference's own test image (data/frc_balls.png, committed as a fixture under tests/golden/) resized to the
+    configuration's input size - the frame SURVEY.md §8(c)'s restated acceptance target is quoted on. None if absent."""
+    path = os.path.join(ROOT, "tests", "golden", "frc_balls.png")
+    try:
+        import numpy as np
+        from PIL import Image
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB").resize((size, size), Image.BILINEAR))[None])
+    except Exception:   # noqa: BLE001 - the bench then reports the synthetic frame only
+        return None
+
+
+def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, backbone=50, fp8_layers=None, accept=None):
     """The CPU oracle ("port": oracle/orc_net.c + orc_detect.c, the checker, never the product) timed on ALL of
     this host's cores on a bounded sample of the same workload: whole frames (forward + tail) until ~budget_s
     seconds have elapsed; beside it one frame at the reference's 4 threads (src/yolact.rs:34), one at 16, and a
@@ -388,8 +418,15 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, ba
                               max_abs_diff_vs_oracle_f32=[round(float(np.abs(a.numpy() - b).max()), 6) for a, b in zip(th, f32)])
     except Exception as e:   # noqa: BLE001 - reported in the line, never fatal for the GPU measurement
         r["torch_cpu"] = dict(error=str(e)[:200])
+    if accept is not None and not fp8_layers:
+        # the restated acceptance target: the reference's test image at this input size, engine vs oracle
+        frame, dets = accept
+        h = net.forward(frame, f16=True, nthreads=cores)
+        r["engine_vs_oracle_frc_balls"] = accuracy_vs_oracle(dets, O.detect(h[0][0], h[1][0], h[2][0], h[3][0], pri))
+        r["engine_vs_oracle_frc_balls"]["frame"] = f"tests/golden/frc_balls.png resized to {frame.shape[1]}x{frame.shape[2]} (bilinear)"
     if eng_out is not None and not fp8_layers:
         r["engine_vs_oracle_same_frame"] = accuracy_vs_oracle(eng_out, first)
+        r["engine_vs_oracle_same_frame"]["frame"] = "synthetic frame 0 of the bench (uniform noise): the CPU sample's frame"
     elif eng_out is not None:
         # configs[4]: the engine ran its fp8 form; the oracle's fp8 mode with the engine's calibrated scales is its
         # checker, and the gap to the f16 oracle is a reported property of the configuration
@@ -469,6 +506,10 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
         progress(f"batch {batch}: final frame-0 detections")
         eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
         aux["dets_frame0"] = eng.detections(0, want_masks=True)
+        acc_img = acceptance_frame(size)
+        if acc_img is not None:
+            eng.set_input(acc_img); eng.evaluate(); eng.sync()
+            aux["accept"] = (acc_img, eng.detections(0, want_masks=True))
         aux["fp8_layers"] = eng.fp8_layers() if precision == "fp8" else None
     if dist is not None:
         dist.barrier()
@@ -567,7 +608,7 @@ def main():
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"], backbone=a.backbone,
-                                            fp8_layers=aux.get("fp8_layers"))
+                                            fp8_layers=aux.get("fp8_layers"), accept=aux.get("accept"))
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -96,7 +96,9 @@ typedef struct yh_tuning {
                               * creation time only */
     int32_t headfork_maxb;   /* batches up to this size run the prediction head (and the tail's K1-K3) on the second stream
                               * beside the protonet (default: every batch size); 0: never (the tail's K1-K3 alone fork) */
-    int32_t reserved[4];     /* -1 */
+    int32_t protofuse;       /* the 1x1 conv that makes the 32 prototypes evaluated in the epilogue of the 3x3 conv in front of it
+                              * wherever that one runs as single 256 x 256-tile launches (1); creation time only */
+    int32_t reserved[3];     /* -1 */
 } yh_tuning;
 
 typedef struct yh_config {

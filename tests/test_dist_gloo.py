@@ -95,6 +95,14 @@ def test_accuracy_helper_matches_by_class_and_prior():
     assert same["mask_iou_all"] == 1.0 and same["unmatched_oracle"] == 0
     e = bench.accuracy_vs_oracle(([], m[:0]), ([], m[:0]))
     assert e["mask_iou_matched"] is None and e["mask_iou_all"] is None
+    # full lists whose last places swap at the cut (scores equal to the 4th decimal): the *_above_cut pair leaves the tie out
+    m3 = np.concatenate([m, np.ones((1, 4, 4), np.uint8)])
+    a = ([dict(class_id=3, prior=7, score=0.9), dict(class_id=5, prior=9, score=0.5), dict(class_id=8, prior=1, score=0.1001)], m3)
+    b = ([dict(class_id=3, prior=7, score=0.9), dict(class_id=5, prior=9, score=0.5), dict(class_id=9, prior=2, score=0.1002)], m3)
+    r = bench.accuracy_vs_oracle(a, b)
+    assert r["unmatched_oracle"] == 1 and r["mask_iou_all"] < 0.5 and r["mask_iou_above_cut"] == 1.0 and r["unmatched_above_cut"] == 0 and r["dets_above_cut"] == 2
+    b2 = ([dict(class_id=3, prior=7, score=0.9), dict(class_id=6, prior=9, score=0.5), dict(class_id=9, prior=2, score=0.1002)], m3)
+    assert bench.accuracy_vs_oracle(a, b2)["unmatched_above_cut"] == 2          # a real disagreement stays one
 
 
 def test_measured_traffic_reads_the_committed_pmc_file():

@@ -32,8 +32,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(built):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
-    acc = cb["engine_vs_oracle_same_frame"]                       # over ALL detections of both sides (bench.accuracy_vs_oracle)
-    assert acc["mask_iou_all"] >= 0.99 and acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3, acc
+    acc = cb["engine_vs_oracle_frc_balls"]                        # the restated acceptance target, over ALL detections of both sides
+    assert acc["mask_iou_all"] >= 0.99 and acc["unmatched_oracle"] == 0 and acc["unmatched_engine"] == 0 and acc["oracle_dets"] >= 5, acc
+    acc = cb["engine_vs_oracle_same_frame"]                       # a noise frame fills the list: ties at the top-k cut may swap
+    assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and acc["unmatched_above_cut"] == 0 and acc["mask_iou_above_cut"] >= 0.99, acc
     assert b["batch1"]["value"] > 0
 
 

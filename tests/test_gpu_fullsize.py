@@ -66,7 +66,10 @@ def test_one_frame_550_vs_oracle(eng550, oracle, golden_dir):
         acc = bench.accuracy_vs_oracle((dets, masks), (fdets, fmasks))
         assert acc["oracle_dets"] >= min_dets, (name, acc)
         assert acc["unmatched_oracle"] <= max_unmatched and acc["unmatched_engine"] <= max_unmatched, (name, acc)
-        assert acc["mask_iou_all"] >= 0.99, (name, acc)
+        if name == "frc_balls" or acc["unmatched_oracle"] + acc["unmatched_engine"] == 0:
+            assert acc["mask_iou_all"] >= 0.99, (name, acc)
+        else:   # a full list: ties at the top-k cut may swap (bench.accuracy_vs_oracle: the *_above_cut pair leaves them out)
+            assert acc["unmatched_above_cut"] == 0 and acc["mask_iou_above_cut"] >= 0.99, (name, acc)
         # and for EVERY oracle detection the engine's own softmax probability for that (class, prior) agrees
         conf = got[1][0]
         for d in fdets:
@@ -145,7 +148,7 @@ def test_conv_linearity_exact_at_full_layer_size(built, oracle):
 
 # ---- configs[2]: batch 64, hipGraph steady state (BASELINE.json; tiles -> batch entries, src/yolact.rs:216-217) ----
 LAYERS_550 = (("pool", 2e-3), ("c2", 6e-3), ("c3", 1e-2), ("c4", 1.5e-2), ("c5", 2e-2), ("lat5", 2e-2), ("lat4", 2e-2), ("lat3", 2e-2),
-              ("p3", 2e-2), ("p4", 2e-2), ("p5", 2e-2), ("p6", 2.5e-2), ("p7", 2.5e-2), ("proto0", 2.5e-2), ("proto2", 2.5e-2), ("proto3", 3e-2),
+              ("p3", 2e-2), ("p4", 2e-2), ("p5", 2e-2), ("p6", 2.5e-2), ("p7", 2.5e-2), ("proto0", 2.5e-2), ("proto2", 2.5e-2),
               ("head_t0", 3e-2), ("head_t2", 3e-2), ("head_t4", 3e-2))
 
 
@@ -171,7 +174,11 @@ def test_batch64_launch_plans_are_the_ones_the_bench_runs(eng64):
     assert sum("conv_igemm_f16<128,128,2,2,0,1>" in n for n in names) >= 20    # K1 streaming tiles (>= 1024 tiles each)
     assert any(n.endswith("/rounds") for n in names) and any(n.endswith("/tail") for n in names)
     assert any(n.endswith("/ch0-255") for n in names) and any(n.endswith("/ch256-383") for n in names)
-    assert any("conv_igemm_f16<256,256,2,4,0,2,mfma16>" in n and n.endswith(":proto3") for n in names)
+    # the largest conv runs with the 1x1 prototype conv in its epilogue: one launch for both, proto3 itself is never written
+    assert any(n == "conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]:proto3+proto" for n in names) and not any(n.endswith(":proto") for n in names)
+    import yolact_amd as ya
+    with pytest.raises(ya.YhError):
+        eng.tensor_frame("proto3", 0)
     assert not any("splitk" in n for n in names if ":p7" not in n)            # split-K is a small-batch plan
 
 
@@ -227,8 +234,13 @@ def test_batch64_one_slot_layer_by_layer_vs_oracle(eng64, oracle):
         assert np.abs(a - b[0]).max() <= 0.03 * max(1.0, np.abs(b).max()), tn
         assert np.sqrt(((a - b[0]) ** 2).mean()) <= 5e-3 * np.sqrt((b ** 2).mean()) + 1e-4, tn
     fd = oracle.detect(want[0][0], want[1][0], want[2][0], want[3][0], net.priors())
+    # A uniform-noise frame under seeded weights fills the list (100 detections) with scores that differ in the 4th decimal
+    # at the cut, so which candidates take the last places is decided by f16 summation order (this slot: ranks 98 / 99 swap,
+    # and the engine-only one has a frame-sized box) - the acceptance frame (test_one_frame_550_vs_oracle) has no such tie.
+    # Asserted: everything that is not within 2 % of the cut score is matched and its masks agree; at most 3 swaps at the cut.
     acc = bench.accuracy_vs_oracle(eng.detections(slot), fd)
-    assert acc["oracle_dets"] >= 50 and acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and acc["mask_iou_all"] >= 0.99, acc
+    assert acc["oracle_dets"] >= 50 and acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3, acc
+    assert acc["unmatched_above_cut"] == 0 and acc["dets_above_cut"] >= 80 and acc["mask_iou_above_cut"] >= 0.99, acc
 
 
 # ---- configs[4] geometry in f16: YOLACT-700 ResNet-101, one frame ----
@@ -254,7 +266,11 @@ def test_yolact700_r101_one_frame_vs_oracle(built, oracle):
     assert [(d["class_id"], d["prior"], d["score"], d["box"]) for d in dets[0]] == [(d["class_id"], d["prior"], d["score"], d["box"]) for d in odets]
     assert np.array_equal(dets[1], omasks)
     acc = bench.accuracy_vs_oracle(dets, fd)
-    assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and (acc["mask_iou_all"] is None or acc["mask_iou_all"] >= 0.99), acc
+    assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3, acc
+    if acc["unmatched_oracle"] + acc["unmatched_engine"] == 0:
+        assert acc["mask_iou_all"] is None or acc["mask_iou_all"] >= 0.99, acc
+    else:
+        assert acc["unmatched_above_cut"] == 0 and (acc["mask_iou_above_cut"] is None or acc["mask_iou_above_cut"] >= 0.99), acc
     eng.close()
 
 

@@ -258,6 +258,42 @@ def test_projection_shortcut_inside_the_last_conv_matches_the_two_conv_form(buil
         assert np.abs(res[0][1][i] - want[i]).max() <= 0.03 * max(1.0, np.abs(want[i]).max()), i
 
 
+@pytest.mark.parametrize("S2,n,precision", [(128, 2, "f16"), (224, 3, "f16"), (160, 2, "fp8")])
+def test_prototype_conv_in_the_epilogue_of_the_conv_before_it(built, oracle, S2, n, precision):
+    """tune.protofuse (default): where the last 3x3 protonet conv runs as single launches of the 256 x 256 tile, the 1x1
+    conv that makes the 32 prototypes runs in its epilogue on the tile's rounded f16 outputs (ConvParams::w2): proto3 is
+    not written. Planned for a 4-CU chip so that these small tensors take the batch-64 launch forms (f16 tile, and the
+    block-scaled fp8 tile under precision = fp8). Same operands, same f32 accumulation, another summation order:
+    the prototypes agree with the two-launch form within one f16 ulp; every other output keeps its bits."""
+    import yolact_amd as ya
+    img = np.random.default_rng(S2 + 3).integers(0, 256, (n, S2, S2, 3), dtype=np.uint8)
+    outs = []
+    for fuse in (1, 0):
+        eng = ya.Engine(input_size=S2, max_batch=n, use_graph=True, conf_thresh=THRESH, tune=dict(protofuse=fuse, plan_cus=4),
+                        precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16)
+        eng.load_weights(eng.generate_weights(1))
+        eng.set_input(img)
+        if precision == "fp8":
+            eng.fp8_calibrate()
+        for _ in range(2):
+            eng.evaluate()
+        names = [p["name"] for p in eng.profile(with_tail=False, reps=1)]
+        assert any(n_.endswith(":proto3+proto") and "[+1x1]" in n_ for n_ in names) == (fuse == 1)
+        assert any(n_.endswith(":proto") for n_ in names) == (fuse == 0)
+        outs.append([eng.output(i) for i in range(4)])
+        if fuse:
+            with pytest.raises(ya.YhError):
+                eng.tensor("proto3")
+        else:
+            assert np.isfinite(eng.tensor("proto3")).all()
+        eng.close()
+    for i in range(3):
+        assert np.array_equal(outs[0][i], outs[1][i])
+    a, b = outs[0][3], outs[1][3]
+    assert a.shape == b.shape and np.all(np.abs(a - b) <= 2.0 ** -10 * np.maximum(np.abs(b), 1.0) + 1e-3)
+    assert np.abs(b).max() > 0.1
+
+
 def test_graph_replay_equals_eager(built, golden_dir):
     import yolact_amd as ya
     img = _frames(golden_dir)

@@ -95,9 +95,15 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 // DUAL: two-source 1x1 form (ConvParams::x2): after k-step k1steps - 1 the loader switches to the second tensor - its
 //      per-row source offsets are recomputed IN PLACE at the switch (no registers of their own while the accumulators
 //      are live) and the buffer descriptor is swapped; the weight panel simply continues along K.
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false, bool DUAL = false>
+// TAIL: fused 1x1 tail (ConvParams::w2): the epilogue rounds the accumulators (bias, ReLU) to f16 STRAIGHT into an LDS
+//      image [256 rows][256 ch] (128 KB, the dead ring; 16-byte chunk c of row r at chunk c ^ (r & 15): the lanes' 8-byte
+//      writes and the 16-lane fragment reads are both conflict free) - no f32 staging, no rounds - and the eight waves
+//      run the 32 x 256 second convolution on it with v_mfma_f32_16x16x32_f16 (weights = A straight from L2: 16 KB in
+//      all). The first conv's output never leaves the CU.
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false, bool DUAL = false, bool TAIL = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
+    static_assert(!TAIL || (TCH == 256 && TM == 256 && WCH * WM == 8 && MT == 16 && !SPLITK && !RESUP && !DUAL && !ML), "fused 1x1 tail: the 256 x 256 tile of 16x16x32 MFMAs");
     static_assert(!DUAL || (!ML && !SMALLC && !FP8 && !RESUP), "two-source form: plain 1x1 convolutions");
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     constexpr int AB_BYTES = (TCH + TM) * 128;
     constexpr int ES = TCH + 4;                    // epilogue row stride in floats
     constexpr int RING_BYTES = STAGES * AB_BYTES;
-    constexpr int LDS_BYTES = cmax<RING_BYTES, (TM / EPI) * ES * 4>::v;
+    constexpr int LDS_BYTES = cmax<RING_BYTES, TAIL ? TM * 512 : (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
     static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
     static_assert(STAGES == 1 || STAGES == 2 || ((STAGES == 3 || STAGES == 4) && !SMALLC), "ring variants: no ordinary loads may share the loop");
@@ -474,6 +480,60 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         __syncthreads();  // LDS is reused by the epilogue
     }
 
+    if constexpr (TAIL) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        typedef float acc4 __attribute__((ext_vector_type(4)));
+        // (the main loop's last barrier has passed: no wave reads the ring any more)
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int c_l = wc * WTC + i * MT + 4 * lh;
+            const f32x4 b4 = *(const f32x4*)(p.bias + c_l);
+            f32x4 s4 = { 1.0f, 1.0f, 1.0f, 1.0f };
+            if (FP8) s4 = *(const f32x4*)(p.scale + c_l);
+#pragma unroll
+            for (int j = 0; j < TMT; ++j) {
+                const int m_l = wm * WTM + j * MT + l31;
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = FP8 ? __builtin_fmaf(acc[i][j][e], s4[e], b4[e]) : acc[i][j][e] + b4[e];
+                    if (p.act == 1) v = fmaxf(v, 0.0f);
+                    o[e] = (half_t)v;
+                }
+                *(half4*)(lds + m_l * 512 + (((c_l >> 3) ^ (m_l & 15)) << 4) + (c_l & 4) * 2) = o;
+            }
+        }
+        __syncthreads();
+        // second convolution: wave w -> rows 32 w .. 32 w + 31 (two 16-row pixel tiles), both 16-channel tiles
+        const int w8 = tid >> 6;
+        half8 af[2][8];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) af[ct][k2] = *(const half8*)(p.w2 + (ct * 16 + l31) * 256 + k2 * 32 + lh * 8);
+        const f32x4 bb0 = *(const f32x4*)(p.bias2 + 4 * lh), bb1 = *(const f32x4*)(p.bias2 + 16 + 4 * lh);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int row = w8 * 32 + pt * 16 + l31;
+            const char* yrow = lds + row * 512;
+            acc4 a0 = { 0.0f, 0.0f, 0.0f, 0.0f }, a1 = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const half8 bf = *(const half8*)(yrow + (((k2 * 4 + lh) ^ l31) << 4));
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][k2], bf, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1][k2], bf, a1, 0, 0, 0);
+            }
+            const int m2 = m_tile * TM + row;   // lane: pixel `row`, channels 4 lh .. + 3 of each 16-channel tile
+            if (m2 < p.M) {
+                half4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o0[e] = (half_t)fmaxf(a0[e] + bb0[e], 0.0f); o1[e] = (half_t)fmaxf(a1[e] + bb1[e], 0.0f); }
+                *(half4*)(p.y2 + (long long)m2 * 32 + 4 * lh) = o0;
+                *(half4*)(p.y2 + (long long)m2 * 32 + 16 + 4 * lh) = o1;
+            }
+        }
+        return;
+    }
     // ---- epilogue: accumulators -> LDS f32 [m][ch] (TM / EPI rows per round), then coalesced rows
     float* E = (float*)lds;
     float bias8[8];
@@ -854,6 +914,14 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
             case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
             default: return hipErrorInvalidValue;
         }
+        return hipGetLastError();
+    }
+    if (p.w2) {   // fused 1x1 tail: single launches of the 256 x 256 tile whose one channel tile is the whole conv
+        if (p.k_slices > 1 || p.n_ch_tiles != 1 || p.ch_tile0 || p.cout8 != 256 || p.res || p.x2 || p.nlev || !p.bias2 || !p.y2 || p.y || p.y8 || p.tanh_from < 256) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)(n_m_tiles * p.n_ch_tiles));
+        if (tile == TILE_256x256_M16) hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, false, false, false, true>), grid, dim3(512), 0, stream, p);
+        else if (tile == TILE_256x256_FP8 && p.scale) hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, true, false, false, true>), grid, dim3(512), 0, stream, p);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (p.x2) {   // two-source 1x1 form (a bottleneck block's last conv + its projection): the tiles dual_conv_tile() maps to

@@ -69,6 +69,8 @@ struct Op {
     Buf in, out, res;
     bool has_res = false;
     bool res_up = false;   // the residual is the bilinear resize of the lower-resolution tensor `res` (ConvParams::res_up)
+    int tail_op = -1;      // index of the 1x1 conv that may run in this conv's epilogue (ConvParams::w2) when the launch plan allows
+    int fused_into = -1;   // ... and on that 1x1 conv: the index of the conv that may absorb it
     bool side = false;     // may run on the second stream: nothing on the main stream reads its output before the step's join
     bool dual = false;     // two-source 1x1 form: K continues over `in2` read at `stride2` (ConvParams::x2)
     Buf in2;
@@ -108,7 +110,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -119,7 +121,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
-    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20);
+    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1);
     return r;
 }
 
@@ -565,6 +567,14 @@ int build_graph_spec(yh_engine* h) {
     h->ops.push_back(conv_op(h, "proto3", add_panel(h, { ci++ }), pup, p3b, 1, 1, 1, nullptr));
     if ((rc = new_buf(h, "proto", h->hp, h->wp, 32, &h->proto))) return rc;
     h->ops.push_back(conv_op(h, "proto", add_panel(h, { ci++ }), p3b, h->proto, 1, 0, 1, nullptr));
+    // tune.protofuse (default): where proto3 runs as single launches of the 256 x 256 tile (every batch size from about 8
+    // on), the 1x1 conv that makes the 32 prototypes runs in its epilogue on the tile's rounded outputs - proto3 (256
+    // channels at 138 x 138: 624 MB at batch 64) is neither written nor read back. debug_tensors = 1 keeps the two launches.
+    if (h->tune.protofuse && !h->cfg.debug_tensors && h->panels[h->ops.back().panel].cout == 32 && h->proto.img_stride == (long long)h->hp * h->wp * 32) {
+        const int i1 = (int)h->ops.size() - 1;
+        h->ops[i1 - 1].tail_op = i1;
+        h->ops[i1].fused_into = i1 - 1;
+    }
     ci = ci_end;
     if (ci != (int)h->convs.size()) return h->fail(YH_EINVAL, "conv table / graph mismatch");
     h->flops_per_frame = 0;
@@ -877,6 +887,14 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     if (tile_out) *tile_out = tile;
     p.n_ch_tiles = pn.coutPad / conv_tile_ch(tile);
     p.k_slices = 1;
+    if (o.tail_op >= 0 && (tile == TILE_256x256_M16 || tile == TILE_256x256_FP8) && pn.coutPad == 256 && pn.cout == 256 && !o.has_res &&
+        tail_split_tiles(h->tune, pn.coutPad, p, tile) == 0) {
+        // fused 1x1 tail: this launch also computes ops[tail_op] from its tile (launch_op skips that op: conv_absorbed)
+        const Op& t = h->ops[o.tail_op];
+        const Panel& p2 = h->panels[t.panel];
+        p.w2 = p2.w; p.bias2 = p2.bias; p.y2 = t.out.d;
+        p.y = nullptr; p.y8 = nullptr;
+    }
     const int splitk_min = h->tune.splitk_minsteps, t64_mode = h->tune.t64, t64_min = h->tune.t64_minsteps;
     const bool ring128 = tile == TILE_128x128_S3 || tile == TILE_128x128_S4;
     const bool ring64 = (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && t64_mode >= 2;
@@ -902,8 +920,16 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
 }
 
 // side: the op runs on the side stream (with that stream's split-K workspace) - convolutions only
+// Is this 1x1 conv computed in the epilogue of the conv in front of it at batch n?
+bool conv_absorbed(yh_engine* h, const Op& o, int n) {
+    if (o.fused_into < 0) return false;
+    ConvParams p;
+    return fill_conv_params(h, h->ops[o.fused_into], n, &p) == YH_OK && p.w2 != nullptr;
+}
+
 int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
     hipError_t e = hipSuccess;
+    if (o.kind == OP_CONV && conv_absorbed(h, o, n)) return YH_OK;
     if (side && o.kind != OP_CONV) return h->fail(YH_EINVAL, "only convolutions fork onto the side stream");
     switch (o.kind) {
         case OP_PRE:
@@ -1320,7 +1346,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse;
     return YH_OK;
 }
 
@@ -1829,9 +1855,17 @@ int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, 
 int yh_debug_last_conv_launches(const yh_engine* h) { return h ? h->last_conv_launches : 0; }
 const uint32_t* yh_classify_device_frame(const yh_engine* h) { return h ? h->frame_dev : nullptr; }
 
+// Is `name` the output of a conv whose 1x1 tail ran in its epilogue at the current batch size (the tensor was not written)?
+static bool absorbed_output(yh_engine* h, const char* name) {
+    if (h->cur_n < 1) return false;
+    for (const Op& o : h->ops)
+        if (o.kind == OP_CONV && o.tail_op >= 0 && o.name == name) return conv_absorbed(h, h->ops[o.tail_op], h->cur_n);
+    return false;
+}
+
 int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;
-    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+    if ((h->fused_away.count(name) && !h->cfg.debug_tensors) || absorbed_output(h, name))
         return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
@@ -1859,7 +1893,7 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
 
 int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, float* dst, size_t nfloats, int32_t dims[4]) {
     if (!h || !name || !dims) return YH_EINVAL;
-    if (h->fused_away.count(name) && !h->cfg.debug_tensors)
+    if ((h->fused_away.count(name) && !h->cfg.debug_tensors) || absorbed_output(h, name))
         return h->fail(YH_ESTATE, std::string("the ") + name + " tensor is fused away; create the engine with debug_tensors = 1 to materialise it");
     auto it = h->named.find(name);
     if (it == h->named.end()) return h->fail(YH_EINVAL, std::string("unknown tensor ") + name);
@@ -1894,6 +1928,7 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
     for (int i = 0; i < (int)h->ops.size(); ++i) {
         const Op& o = h->ops[i];
         if (o.kind != OP_CONV) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }
+        if (conv_absorbed(h, o, n)) continue;   // (accounted with the launch that computes it)
         ConvParams p;
         ConvTile tile;
         const int rc = fill_conv_params(h, o, n, &p, &tile);
@@ -1959,7 +1994,13 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 by = (double)pe.k.p.M * pe.k.p.partial_ld * 4.0 * pe.k.p.k_slices + (double)pe.k.p.M * pe.k.p.cout8 * 2.0;
             } else if (pe.is_conv) {
                 // (the multi-level instantiation is a kernel symbol of its own in rocprofv3's stats)
-                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + (pe.k.p.nlev > 0 ? "[ml]" : "") + ":" + o.name + pe.k.what;
+                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + (pe.k.p.nlev > 0 ? "[ml]" : "") + (pe.k.p.w2 ? "[+1x1]" : "") + ":" + o.name + pe.k.what;
+                if (pe.k.p.w2) {   // fused 1x1 tail: both convolutions' FLOPs; this conv's input and the tail's output
+                    const Op& t = h->ops[o.tail_op];
+                    h->prof_labels[i] += "+" + t.name;
+                    fl += t.flops_per_img * n;
+                    by += t.bytes_fixed + 2.0 * n * ((double)t.P * t.Q * h->panels[t.panel].cout - (double)o.P * o.Q * h->panels[o.panel].cout * (h->fp8_active && !o.write_f16 ? 0.0 : 1.0));
+                }
             } else h->prof_labels[i] = o.label;
         } else h->prof_labels[i] = detect_stage_name(pe.stage);
         if (flops) flops[i] = fl;

@@ -57,6 +57,12 @@ struct ConvParams {
     long long x2_img_stride;
     unsigned x2_bytes, x2_zero_off;
     int W2, C2, stride2, k1steps;
+    // fused 1x1 tail (w2 != nullptr; 256-channel tiles that hold ALL of this conv's output channels): the tile's rounded
+    // f16 outputs stay in LDS and a second convolution y2[m][0..31] = relu(bias2 + sum_c w2[o][c] * y[m][c]) runs on them
+    // in the epilogue (protonet: the last 3x3 conv and the 1x1 that makes the 32 prototypes); y may then be nullptr.
+    const half_t* w2;     // [32][256] f16
+    const float* bias2;   // [32]
+    half_t* y2;           // [M][32] dense
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
