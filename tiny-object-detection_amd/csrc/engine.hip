@@ -1326,8 +1326,8 @@ int yh_set_tuning(yh_engine* h, const yh_tuning* tune) {
     if (!h || !tune) return YH_EINVAL;
     const Tune t = resolve_tuning(*tune, h->device_cus);
     if (t.bigk != h->tune.bigk || t.stemfuse != h->tune.stemfuse || t.prefuse != h->tune.prefuse || t.headmerge != h->tune.headmerge ||
-        t.upfuse != h->tune.upfuse)
-        return h->fail(YH_ESTATE, "bigk, stemfuse, prefuse, headmerge and upfuse are fixed when the handle is created");
+        t.upfuse != h->tune.upfuse || t.dsfuse != h->tune.dsfuse || t.protofuse != h->tune.protofuse)
+        return h->fail(YH_ESTATE, "bigk, stemfuse, prefuse, headmerge, upfuse, dsfuse and protofuse are fixed when the handle is created");
     HIPCHK(h, hipSetDevice(h->dev));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // captured plans were made under the old tuning
