@@ -13,7 +13,10 @@ def symbol(name):
         if len(a) >= 9 and a[8] == "16":
             s += ",mfma16"
         ml = "[ml]" if len(a) >= 10 and a[9] == "1" else ""
-        return f"conv_igemm_f16<{s}>{ml}"
+        tail = "[+1x1]" if len(a) >= 14 and a[13] == "1" else ""   # fused 1x1 tail (conv_igemm.hip: TAIL)
+        if len(a) >= 11 and a[10] == "1":                          # fp8 operands: the engine's label for this instantiation
+            return f"conv_igemm_fp8<{','.join(a[:4])}>{ml}{tail}"
+        return f"conv_igemm_f16<{s}>{ml}{tail}"
     m = re.search(r"(?:yh::|_ZN2yh\d+)([a-z_0-9]+)", name)
     return m.group(1) if m else name[:40]
 
