@@ -231,6 +231,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         }
     };
     auto tile_part = [&](int buf, int d) {
+        if (p.skip_dma) return;
         lds_char* const dstw = lds3 + buf * AB_BYTES + wave * 1024;
         if (d < WL) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, dstw + d * (RSTEP * 128), 16,

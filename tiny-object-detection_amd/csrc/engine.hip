@@ -864,6 +864,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     // timing-only ablation (tune.ablate): zero-record descriptors drop every load through them
     if (h->tune.ablate & 1) { p.x_bytes = 0; }
     if (h->tune.ablate & 2) { p.w_bytes = 0; }
+    if (h->tune.ablate & 4) { p.skip_dma = 1; }
     ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
     if (o.dual) tile = dual_conv_tile(tile);
     if (h->fp8_active) {

@@ -63,6 +63,7 @@ struct ConvParams {
     const half_t* w2;     // [32][256] f16
     const float* bias2;   // [32]
     half_t* y2;           // [M][32] dense
+    int skip_dma;         // timing only (tune.ablate bit 2): the loader issues NO LDS-DMA instruction (results are garbage)
     int cout8;            // output channels rounded up to 8 (stores happen in 8-channel chunks)
     int ldw;              // Kpad
     int ksteps;           // Kpad / 64
