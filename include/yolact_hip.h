@@ -84,7 +84,8 @@ typedef struct yh_tuning {
     int32_t upfuse;          /* FPN top-down upsamples evaluated in the lateral conv's epilogue instead of a kernel and a
                               * tensor of their own (1); creation time only */
     int32_t k1_generic;      /* the generic softmax/candidate kernel also for 81 classes (0) */
-    int32_t ablate;          /* timing only: bit 0 / bit 1 drop the activation / weight stream (results are garbage) */
+    int32_t ablate;          /* timing only (results are garbage): bit 0 / bit 1 drop the activation / weight stream (zero-record
+                              * descriptors: the loads issue, nothing moves), bit 2 issues no loader instruction at all */
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
     int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
