@@ -117,7 +117,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     Tune r;
     r.plan_cus = t.plan_cus > 0 ? t.plan_cus : device_cus;
     r.mfma16 = d(t.mfma16, 1); r.t128x256_m16 = d(t.t128x256_m16, 1); r.small16 = d(t.small16, 0); r.bigk = d(t.bigk, 256);
-    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 3); r.k1_maxk = d(t.k1_maxk, 1024);
+    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 5); r.k1_maxk = d(t.k1_maxk, 1024);
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
@@ -719,7 +719,8 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // HBM-bound 1x1 layers (K <= 512): the single-stage "streaming" forms keep 34-40 KB of LDS per workgroup,
     // so four workgroups share a CU instead of two and their load and store phases overlap each other
     // (4.0 -> 5.2 TB/s on the 69 x 69 expand convs at batch 64). tune.k1tile: 0 off, 1: 128x128 form only,
-    // 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3.
+    // 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3, 4: also 128-channel 3x3, 5: also 256-channel 3x3 layers with
+    // fewer than two rounds of big tiles.
     const int k1 = tu.k1tile;
     const long long k1_min = 4ll * tu.plan_cus;   // (1024 tiles on the 256-CU part)
     if (k1 && !ml && pn.k == 1 && pn.Kpad <= tu.k1_maxk) {
@@ -729,6 +730,12 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // (the 64-channel 3x3 convs of layer 1 too: 590 -> 715 TFLOP/s - their LDS fill per MFMA is what binds them, and
     // four co-resident workgroups overlap it better than a double buffer inside two)
     if (k1 >= 3 && !ml && pn.k == 3 && pn.tile == TILE_64x256 && (M + 255) / 256 >= k1_min) return TILE_64x256_K1;
+    // ... and the 128-channel 3x3 convs of layer 2 (k1 >= 4: 0.118 -> 0.098 ms, 918 TFLOP/s where the 8-wave 128 x 256 forms
+    // gave 740-775), and 256-channel 3x3 layers whose big tiles are fewer than two rounds (k1 >= 5; the 35 x 35 layers at
+    // batch 64: 307 tiles of 256 x 256 = a /rounds + /tail pair, 0.107 ms -> one launch of 1226 small tiles, 0.104 ms)
+    if (k1 >= 4 && !ml && pn.k == 3 && pn.tile == TILE_128x256 && pn.coutPad == 128 && (long long)((M + 127) / 128) >= k1_min) return TILE_128x128_K1;
+    if (k1 >= 5 && !ml && pn.k == 3 && pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) < 2ll * tu.plan_cus &&
+        (long long)((M + 127) / 128) * (pn.coutPad / 128) >= 5ll * tu.plan_cus / 2) return TILE_128x128_K1;
     // 64-channel layers at small batch (layer 1 at batch 1: 75 tiles of 64 x 256 on 256 CUs): 64 x 64 tiles make four
     // times the workgroups
     if (tu.t64 && !ml && pn.tile == TILE_64x256 && (M + 255) / 256 < tu.plan_cus) return TILE_64x64_S3;
