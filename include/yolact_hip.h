@@ -71,7 +71,8 @@ typedef struct yh_tuning {
     int32_t tailsplit;       /* two-phase launches against wave quantisation (1) */
     int32_t chsplit;         /* 256 + 128 channel split of the 384-channel head (1) */
     int32_t k1tile;          /* single-stage streaming tiles (four workgroups per CU): 0 off, 1 1x1 layers on the 128x128 form,
-                              * 2 + 64-channel 1x1, 3 + 64-channel 3x3, 4 + 128-channel 3x3, 5 + 3x3 layers with few big tiles (5) */
+                              * 2 + 64-channel 1x1, 3 + 64-channel 3x3, 4 + 128-channel 3x3, 5 / 6 + 3x3 layers with few big tiles and
+                              * the head's 128-channel remainder (6) */
     int32_t k1_maxk;         /* ... for 1x1 layers with K <= this (1024) */
     int32_t splitk_minsteps; /* K-steps from which few-tile launches split K (12) */
     int32_t t64;             /* 64x64 tiles for latency-bound launches: 0 off, 1 never split K, 2 split K (2) */

@@ -909,6 +909,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
             case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16, true>), grid, dim3(512), 0, stream, p); break;
             case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1, false, 32, true>), grid, dim3(512), 0, stream, p); break;
             case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;

@@ -117,7 +117,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     Tune r;
     r.plan_cus = t.plan_cus > 0 ? t.plan_cus : device_cus;
     r.mfma16 = d(t.mfma16, 1); r.t128x256_m16 = d(t.t128x256_m16, 1); r.small16 = d(t.small16, 0); r.bigk = d(t.bigk, 256);
-    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 5); r.k1_maxk = d(t.k1_maxk, 1024);
+    r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 6); r.k1_maxk = d(t.k1_maxk, 1024);
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
@@ -713,6 +713,9 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
             // latency-bound launches (at most one workgroup per CU): the 3-stage ring hides the
             // L2 round trip of every 64-deep K step
             const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
+            // (3x3 layers with too few big tiles but >= 2.5 small ones per CU - layer 4 at batch 64, 648 tiles: the streaming
+            // form, four workgroups per CU, runs them at 950 TFLOP/s where the double-buffered 128 x 128 tile gave 730)
+            if (tu.k1tile >= 6 && !ml && pn.k == 3 && b128 >= 5ll * tu.plan_cus / 2) return TILE_128x128_K1;
             return b128 <= tu.plan_cus ? TILE_128x128_S3 : TILE_128x128;
         }
     }
@@ -720,7 +723,8 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // so four workgroups share a CU instead of two and their load and store phases overlap each other
     // (4.0 -> 5.2 TB/s on the 69 x 69 expand convs at batch 64). tune.k1tile: 0 off, 1: 128x128 form only,
     // 2: also the 64-channel 1x1 form, 3: also 64-channel 3x3, 4: also 128-channel 3x3, 5: also 256-channel 3x3 layers with
-    // fewer than two rounds of big tiles.
+    // fewer than two rounds of big tiles, 6: also 3x3 layers with less than a round of big tiles (layer 4) and the head's
+    // 128-channel remainder (plan_conv).
     const int k1 = tu.k1tile;
     const long long k1_min = 4ll * tu.plan_cus;   // (1024 tiles on the 256-CU part)
     if (k1 && !ml && pn.k == 1 && pn.Kpad <= tu.k1_maxk) {
@@ -791,8 +795,9 @@ int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, K
         a.n_ch_tiles = 1;
         b.n_ch_tiles = 1; b.ch_tile0 = 2;
         out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
-        // the 128-channel remainder on the 4-wave 128 x 128 tile (two workgroups per CU: 0.34 -> 0.30 ms at batch 64)
-        out[1] = KLaunch{ false, b, TILE_128x128, 128.0 / 384.0, "/ch256-383" };
+        // the 128-channel remainder on the 4-wave 128 x 128 tile (two workgroups per CU: 0.34 -> 0.30 ms at batch 64), in its
+        // streaming form where the launch is large (four per CU: 0.31 -> 0.26 ms)
+        out[1] = KLaunch{ false, b, tu.k1tile >= 6 && (long long)((p.M + 127) / 128) >= 5ll * tu.plan_cus / 2 ? TILE_128x128_K1 : TILE_128x128, 128.0 / 384.0, "/ch256-383" };
         return 2;
     }
     const int mt1 = tail_split_tiles(tu, coutPad, p, tile);
