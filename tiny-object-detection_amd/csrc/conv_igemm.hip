@@ -100,11 +100,14 @@ __device__ __forceinline__ ACC mfma_f16(const half8 a, const half8 b, const ACC 
 //      writes and the 16-lane fragment reads are both conflict free) - no f32 staging, no rounds - and the eight waves
 //      run the 32 x 256 second convolution on it with v_mfma_f32_16x16x32_f16 (weights = A straight from L2: 16 KB in
 //      all). The first conv's output never leaves the CU.
-template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false, bool DUAL = false, bool TAIL = false>
+template <int TCH, int TM, int WCH, int WM, bool SMALLC, int STAGES, int EPI, bool SPLITK = false, int MT = 32, bool ML = false, bool FP8 = false, bool RESUP = false, bool DUAL = false, bool TAIL = false, bool K3 = false>
 __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvParams p) {
     static_assert(!ML || !SMALLC, "multi-level input: ordinary channel counts only");
     static_assert(!TAIL || (TCH == 256 && TM == 256 && WCH * WM == 8 && MT == 16 && !SPLITK && !RESUP && !DUAL && !ML), "fused 1x1 tail: the 256 x 256 tile of 16x16x32 MFMAs");
     static_assert(!DUAL || (!ML && !SMALLC && !FP8 && !RESUP), "two-source form: plain 1x1 convolutions");
+    // K3: the 3x3 specialisation of the streaming tile (kernel extent known at compile time) - a kernel symbol of its own,
+    // so that the MFMA-leaning 3x3 launches and the HBM-bound 1x1 launches of that tile are told apart in every profile
+    const int kR = K3 ? 3 : p.R, kS = K3 ? 3 : p.S;
     constexpr int NW = WCH * WM, NT = NW * 64, RSTEP = NW * 8;  // waves, threads, rows per DMA pass
     constexpr int WTC = TCH / WCH, WTM = TM / WM;  // wave tile
     constexpr int TC = WTC / MT, TMT = WTM / MT;   // MFMA tiles per wave
@@ -189,10 +192,10 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // position of the NEXT tile to load along K
     int kr = 0, ks = 0, kc = 0, kt_load = kt0;
     if (SPLITK && !SMALLC) {
-        const int taps = p.R * p.S, cb = kt0 / taps, rs = kt0 - cb * taps;
+        const int taps = kR * kS, cb = kt0 / taps, rs = kt0 - cb * taps;
         kc = cb << 6;
-        kr = rs / p.S;
-        ks = rs - kr * p.S;
+        kr = rs / kS;
+        ks = rs - kr * kS;
     }
     // DUAL: from k-step k1steps on, the rows come from the second tensor (1x1, no padding: a row is in the image or past M)
     auto second_source = [&]() {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
         } else {
             t_r = kr; t_s = ks; kc_cur = kc;
             t_off = (kr * p.W + ks) * p.C + kc;
-            t_wk = (kr * p.S + ks) * p.C + kc;   // K index of this step in the [(r,s,c)] weight panel
+            t_wk = (kr * kS + ks) * p.C + kc;   // K index of this step in the [(r,s,c)] weight panel
             if (DUAL) t_wk = wk_shift + kc;
         }
     };
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             // input lines (shifted by one pixel / one row) in consecutive steps, so per XCD the
             // live set is ~(tile pixels + halo) * 128 B * 32 CUs + the chunk's weights: it fits
             // the 4 MiB L2, where tap-outer order streamed ~8 MB between two uses of a line.
-            if (++ks == p.S) { ks = 0; if (++kr == p.R) { kr = 0; kc += 64; } }
+            if (++ks == kS) { ks = 0; if (++kr == kR) { kr = 0; kc += 64; } }
         }
         if (DUAL && kt_load == p.k1steps) second_source();
     };
@@ -976,7 +979,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     }
     switch (tile) {
         case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
-        case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2>), grid, dim3(256), 0, stream, p); break;
+        case TILE_128x128_K1:
+            if (p.R == 3 && p.S == 3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, false, false, false, false, false, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2>), grid, dim3(256), 0, stream, p);
+            break;
         case TILE_64x256_K1: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 1, 2>), grid, dim3(256), 0, stream, p); break;
         case TILE_64x256: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_32x256: hipLaunchKernelGGL((conv_igemm_f16<32, 256, 1, 4, false, 2, 1>), grid, dim3(256), 0, stream, p); break;

@@ -2006,8 +2006,9 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 h->prof_labels[i] = "splitk_reduce_f16:" + o.name;
                 by = (double)pe.k.p.M * pe.k.p.partial_ld * 4.0 * pe.k.p.k_slices + (double)pe.k.p.M * pe.k.p.cout8 * 2.0;
             } else if (pe.is_conv) {
-                // (the multi-level instantiation is a kernel symbol of its own in rocprofv3's stats)
-                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + (pe.k.p.nlev > 0 ? "[ml]" : "") + (pe.k.p.w2 ? "[+1x1]" : "") + ":" + o.name + pe.k.what;
+                // (kernel symbols of their own in rocprofv3's stats: multi-level, fused 1x1 tail, the streaming tile's 3x3 form)
+                const bool k3 = pe.k.tile == TILE_128x128_K1 && pe.k.p.R == 3 && pe.k.p.S == 3 && pe.k.p.nlev == 0 && !pe.k.p.res_up && !pe.k.p.x2;
+                h->prof_labels[i] = std::string(conv_tile_symbol(pe.k.tile)) + (pe.k.p.nlev > 0 ? "[ml]" : "") + (pe.k.p.w2 ? "[+1x1]" : "") + (k3 ? "[3x3]" : "") + ":" + o.name + pe.k.what;
                 if (pe.k.p.w2) {   // fused 1x1 tail: both convolutions' FLOPs; this conv's input and the tail's output
                     const Op& t = h->ops[o.tail_op];
                     h->prof_labels[i] += "+" + t.name;

@@ -14,6 +14,8 @@ def symbol(name):
             s += ",mfma16"
         ml = "[ml]" if len(a) >= 10 and a[9] == "1" else ""
         tail = "[+1x1]" if len(a) >= 14 and a[13] == "1" else ""   # fused 1x1 tail (conv_igemm.hip: TAIL)
+        if len(a) >= 15 and a[14] == "1":
+            tail += "[3x3]"                                         # the streaming tile's 3x3 specialisation (K3)
         if len(a) >= 11 and a[10] == "1":                          # fp8 operands: the engine's label for this instantiation
             return f"conv_igemm_fp8<{','.join(a[:4])}>{ml}{tail}"
         return f"conv_igemm_f16<{s}>{ml}{tail}"
