@@ -101,7 +101,10 @@ typedef struct yh_tuning {
                               * beside the protonet (default: every batch size); 0: never (the tail's K1-K3 alone fork) */
     int32_t protofuse;       /* the 1x1 conv that makes the 32 prototypes evaluated in the epilogue of the 3x3 conv in front of it
                               * wherever that one runs as single 256 x 256-tile launches (1); creation time only */
-    int32_t reserved[3];     /* -1 */
+    int32_t k1_min1;         /* streaming tiles: launches of at least this many tiles per CU, in QUARTERS (8 = 2 per CU), for the 1x1
+                              * layers and the 64- / 128-channel 3x3 layers */
+    int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
+    int32_t reserved[1];     /* -1 */
 } yh_tuning;
 
 typedef struct yh_config {

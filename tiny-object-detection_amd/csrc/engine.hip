@@ -110,7 +110,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -121,7 +121,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
-    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1);
+    r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     return r;
 }
 
@@ -715,7 +715,7 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
             const long long b128 = (long long)((M + 127) / 128) * (pn.coutPad / 128);
             // (3x3 layers with too few big tiles but >= 2.5 small ones per CU - layer 4 at batch 64, 648 tiles: the streaming
             // form, four workgroups per CU, runs them at 950 TFLOP/s where the double-buffered 128 x 128 tile gave 730)
-            if (tu.k1tile >= 6 && !ml && pn.k == 3 && b128 >= 5ll * tu.plan_cus / 2) return TILE_128x128_K1;
+            if (tu.k1tile >= 6 && !ml && pn.k == 3 && b128 >= (long long)tu.k1_min3 * tu.plan_cus / 4) return TILE_128x128_K1;
             return b128 <= tu.plan_cus ? TILE_128x128_S3 : TILE_128x128;
         }
     }
@@ -726,7 +726,7 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // fewer than two rounds of big tiles, 6: also 3x3 layers with less than a round of big tiles (layer 4) and the head's
     // 128-channel remainder (plan_conv).
     const int k1 = tu.k1tile;
-    const long long k1_min = 4ll * tu.plan_cus;   // (1024 tiles on the 256-CU part)
+    const long long k1_min = (long long)tu.k1_min1 * tu.plan_cus / 4;   // (tune.k1_min1 = 8 quarter-CUs: two tiles per CU. Four measured the same at batch 64 and 4 % slower at batch 16)
     if (k1 && !ml && pn.k == 1 && pn.Kpad <= tu.k1_maxk) {
         if (pn.coutPad % 128 == 0 && pn.cout > 64 && (long long)((M + 127) / 128) * (pn.coutPad / 128) >= k1_min) return TILE_128x128_K1;
         if (k1 >= 2 && pn.tile == TILE_64x256 && (M + 255) / 256 >= k1_min) return TILE_64x256_K1;
@@ -739,7 +739,7 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
     // batch 64: 307 tiles of 256 x 256 = a /rounds + /tail pair, 0.107 ms -> one launch of 1226 small tiles, 0.104 ms)
     if (k1 >= 4 && !ml && pn.k == 3 && pn.tile == TILE_128x256 && pn.coutPad == 128 && (long long)((M + 127) / 128) >= k1_min) return TILE_128x128_K1;
     if (k1 >= 5 && !ml && pn.k == 3 && pn.tile == TILE_256x256 && (long long)((M + 255) / 256) * (pn.coutPad / 256) < 2ll * tu.plan_cus &&
-        (long long)((M + 127) / 128) * (pn.coutPad / 128) >= 5ll * tu.plan_cus / 2) return TILE_128x128_K1;
+        (long long)((M + 127) / 128) * (pn.coutPad / 128) >= (long long)tu.k1_min3 * tu.plan_cus / 4) return TILE_128x128_K1;
     // 64-channel layers at small batch (layer 1 at batch 1: 75 tiles of 64 x 256 on 256 CUs): 64 x 64 tiles make four
     // times the workgroups
     if (tu.t64 && !ml && pn.tile == TILE_64x256 && (M + 255) / 256 < tu.plan_cus) return TILE_64x64_S3;
@@ -797,7 +797,7 @@ int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, K
         out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
         // the 128-channel remainder on the 4-wave 128 x 128 tile (two workgroups per CU: 0.34 -> 0.30 ms at batch 64), in its
         // streaming form where the launch is large (four per CU: 0.31 -> 0.26 ms)
-        out[1] = KLaunch{ false, b, tu.k1tile >= 6 && (long long)((p.M + 127) / 128) >= 5ll * tu.plan_cus / 2 ? TILE_128x128_K1 : TILE_128x128, 128.0 / 384.0, "/ch256-383" };
+        out[1] = KLaunch{ false, b, tu.k1tile >= 6 && (long long)((p.M + 127) / 128) >= (long long)tu.k1_min3 * tu.plan_cus / 4 ? TILE_128x128_K1 : TILE_128x128, 128.0 / 384.0, "/ch256-383" };
         return 2;
     }
     const int mt1 = tail_split_tiles(tu, coutPad, p, tile);
@@ -1359,7 +1359,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3;
     return YH_OK;
 }
 
