@@ -1219,7 +1219,7 @@ int ensure_out_f32(yh_engine* h, size_t nfloats) {
 // ================================================================================================
 extern "C" {
 
-const char* yh_version(void) { return "yolact-hip 0.1.0 (gfx950, MFMA f16 implicit-GEMM; ABI 1)"; }
+const char* yh_version(void) { return "yolact-hip 0.2.0 (gfx950, MFMA f16 / fp8 implicit-GEMM; ABI 2)"; }
 
 void yh_default_config(yh_config* cfg) {
     memset(cfg, 0, sizeof *cfg);
