@@ -1,0 +1,48 @@
+"""The CPU oracle's network and tail against tests/golden/oracle_network_kat.json - the oracle's own outputs, committed with
+the script that made them (tests/golden/make_oracle_network_kat.py). This pins the CHECKER against drift (an edit of
+oracle/orc_net.c or orc_detect.c, of the build flags, of the weight generator); it is not a reference-held vector - the
+reference has none for the network (parity unpinned). Tolerances leave room for a compiler that contracts
+a*b+c differently (one f16 rounding step of a head value); class ids, priors and the weight bytes are exact."""
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "oracle_network_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def maker(golden_dir):
+    spec = importlib.util.spec_from_file_location("make_oracle_network_kat", os.path.join(golden_dir, "make_oracle_network_kat.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_oracle_reproduces_its_committed_outputs(oracle, kat, maker, i):
+    want = kat["cases"][i]
+    got = maker.case(oracle, want["image"], want["size"], want["backbone"])
+    assert got["weights_sha256"] == want["weights_sha256"]            # the seeded generator: byte for byte
+    for hg, hw in zip(got["heads"], want["heads"]):
+        assert hg["shape"] == hw["shape"] and hg["at"] == hw["at"]
+        assert abs(hg["abs_sum"] - hw["abs_sum"]) <= 1e-4 * hw["abs_sum"] + 1e-6
+        assert abs(hg["sum"] - hw["sum"]) <= 1e-4 * hw["abs_sum"] + 1e-6
+        assert abs(hg["absmax"] - hw["absmax"]) <= 2e-3 * hw["absmax"] + 1e-6
+        assert np.allclose(hg["values"], hw["values"], rtol=2e-3, atol=2e-3)
+    assert [(d["class_id"], d["prior"]) for d in got["dets"]] == [(d["class_id"], d["prior"]) for d in want["dets"]]
+    for dg, dw in zip(got["dets"], want["dets"]):
+        assert abs(dg["score"] - dw["score"]) <= 1e-3 and np.allclose(dg["box"], dw["box"], atol=2e-3)
+        assert abs(dg["mask_pixels"] - dw["mask_pixels"]) <= 0.02 * dw["mask_pixels"] + 4
+
+
+def test_fixture_covers_detections_and_both_backbones(kat):
+    assert {c["backbone"] for c in kat["cases"]} == {50, 101}
+    assert sum(len(c["dets"]) for c in kat["cases"]) >= 100 and any(c["size"] == 550 for c in kat["cases"])
