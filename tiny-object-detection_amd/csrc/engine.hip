@@ -1315,6 +1315,7 @@ void yh_destroy(yh_engine* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->side) hipStreamSynchronize(h->side);   // (every step joins the side stream into the main one; belt and braces before the frees)
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     for (void* p : h->allocs) hipFree(p);
     if (h->out_f32) hipFree(h->out_f32);
