@@ -146,6 +146,33 @@ def test_conv_linearity_exact_at_full_layer_size(built, oracle):
     eng.close()
 
 
+def test_second_stream_changes_no_bit_over_many_steps(built):
+    """The FPN's P4..P7 convolutions, the prediction head and the tail's K1-K3 run on a second stream beside the top-down
+    chain and the protonet (tagged `side` ops, one fork per run, one join before the mask kernel). A missing
+    dependency would show as a bit that differs from the one-stream step: 12 graph-replayed steps on changing frames at
+    full size, batch 8 and batch 1, against an engine with tune.headfork_maxb = 0 and tune.tailfork = 0 - heads, prototypes,
+    detections and masks bitwise equal every time."""
+    import yolact_amd as ya
+    rng = np.random.default_rng(21)
+    for n in (8, 1):
+        two = ya.Engine(input_size=S, max_batch=n, use_graph=True)
+        one = ya.Engine(input_size=S, max_batch=n, use_graph=True, tune=dict(headfork_maxb=0, tailfork=0))
+        blob = two.generate_weights(seed=1)
+        two.load_weights(blob); one.load_weights(blob)
+        for step in range(12):
+            frames = rng.integers(0, 256, (n, S, S, 3), dtype=np.uint8)
+            outs = []
+            for e in (two, one):
+                e.set_input(frames)
+                e.evaluate()
+                outs.append(([e.output(i) for i in range(4)], [e.detections(f) for f in range(n)]))
+            for a, b in zip(outs[0][0], outs[1][0]):
+                assert np.array_equal(a, b), (n, step)
+            for (da, ma), (db, mb) in zip(outs[0][1], outs[1][1]):
+                assert da == db and np.array_equal(ma, mb), (n, step)
+        two.close(); one.close()
+
+
 # ---- configs[2]: batch 64, hipGraph steady state (BASELINE.json; tiles -> batch entries, src/yolact.rs:216-217) ----
 LAYERS_550 = (("pool", 2e-3), ("c2", 6e-3), ("c3", 1e-2), ("c4", 1.5e-2), ("c5", 2e-2), ("lat5", 2e-2), ("lat4", 2e-2), ("lat3", 2e-2),
               ("p3", 2e-2), ("p4", 2e-2), ("p5", 2e-2), ("p6", 2.5e-2), ("p7", 2.5e-2), ("proto0", 2.5e-2), ("proto2", 2.5e-2),
