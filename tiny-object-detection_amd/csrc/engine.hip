@@ -984,23 +984,24 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
 }
 
 int enqueue_all(yh_engine* h, int n, int with_tail) {
-    // One stream, except that the tail's K1-K3 (softmax/append, per-class NMS, frame top-k: small latency-bound
-    // grids that need only the head rows) fork onto the side stream underneath the protonet's convolutions and
-    // join before the mask kernel (event record / wait: valid under stream capture).
-    // The fork pays from batch 4 on and costs nothing below (tune.tailfork = 0 keeps the tail on the main stream).
+    // Two streams. Without the head fork (tune.headfork_maxb = 0) only the tail's K1-K3 (softmax/append, per-class NMS,
+    // frame top-k: small latency-bound grids that need only the head rows) fork onto the side stream underneath the
+    // protonet's convolutions and join before the mask kernel (event record / wait: valid under stream capture);
+    // tune.tailfork = 0 keeps them on the main stream too.
     //
-    // A capture WITHOUT a fork would be a single-branch graph, which the HIP runtime (ROCm 7.2) replays from AQL packets it
-    // pre-built at instantiation. That path is 4 % faster at batch 1 (0.751 vs 0.784 ms) and is NOT used: rocprofv3's
-    // kernel tracing crashes on it, and bench.py's batch-1 leg (host copies and reads between the replays, after an earlier
-    // engine's graphs had been destroyed) ended in a GPU memory access fault on it with kernels and arguments that are
-    // identical to the forked form's (profiles/r02_graph_replay_under_rocprofv3.md). Every capture that has no fork of its
-    // own therefore gets a second branch - a 4-byte memset captured on the side stream - and replays node by node.
+    // tune.headfork_maxb (default: every batch size) forks earlier and more: ops tagged `side` - the FPN's P4..P7
+    // convolutions and the whole prediction head - and then the tail's K1-K3 run on the side stream beside the top-down
+    // chain lat4 -> lat3 -> p3 and the protonet's convolutions, which need only P3. At small batches neither chain fills the
+    // chip (75-300 workgroups per launch at batch 1); at batch 64 each chain's launches fill the other's last, partly empty
+    // rounds. Measured against the tail-only fork on one box: batch 1 0.775 -> 0.725 ms, 4 1.42 -> 1.32, 8 2.08 -> 1.98,
+    // 64 10.47 -> 10.31. Same kernels, same bits (tests/test_gpu_fullsize.py: 12 steps against the one-stream engine).
     //
-    // tune.headfork_maxb (default: every batch size) forks earlier: the whole prediction head (two convolutions over the
-    // pyramid) and then the tail's K1-K3 run on the side stream beside the protonet's six convolutions, which need only
-    // P3. At small batches neither chain fills the chip (75-300 workgroups per launch at batch 1); at batch 64 each chain's
-    // launches fill the other's last, partly empty rounds. Measured against the tail-only fork on one box: batch 1 0.783 ->
-    // 0.756 ms, 4 1.423 -> 1.320, 8 2.084 -> 1.983, 16 3.346 -> 3.295, 64 10.47 -> 10.31. Same kernels, same bits.
+    // A capture WITHOUT any fork would be a single-branch graph, which the HIP runtime (ROCm 7.2) replays from AQL packets it
+    // pre-built at instantiation. That path is 4 % faster at batch 1 and is NOT used: rocprofv3's kernel tracing crashes on
+    // it, and bench.py's batch-1 leg (host copies and reads between the replays, after an earlier engine's graphs had been
+    // destroyed) ended in a GPU memory access fault on it with kernels and arguments that are identical to the forked form's
+    // (profiles/r02_graph_replay_under_rocprofv3.md). Every capture that has no fork of its own therefore gets a second
+    // branch - a 4-byte memset captured on the side stream - and replays node by node.
     bool tail_forked = false;
     const bool fork = h->tune.tailfork != 0;
     const bool headfork = h->tune.headfork_maxb > 0 && n <= h->tune.headfork_maxb;
