@@ -847,12 +847,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64;
                  case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: return 128; case TILE_64x64_S3: case TILE_64x64_S4: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -873,6 +873,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_64x256_K1: return "conv_igemm_f16<64,256,1,4,0,1>";
         case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_128x128_FP8: return "conv_igemm_fp8<128,128,2,2>";
+        case TILE_64x64_FP8: return "conv_igemm_fp8<64,64,2,2>";
         case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
     }
     return "?";
@@ -1004,6 +1005,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_128x128_FP8:   // launches with few 256 x 256 tiles (small batches): four times the workgroups, two per CU
             if (!p.scale) return hipErrorInvalidValue;
             hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
+            break;
+        case TILE_64x64_FP8:     // ... and with at most two 128 x 128 tiles per CU: sixteen times the workgroups
+            if (!p.scale) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 2, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
             break;
         default: return hipErrorInvalidValue;
     }

@@ -895,6 +895,10 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
             // (few 256 x 256 tiles - small batches - leave most CUs idle: 128 x 128 tiles, two workgroups per CU)
             const long long b256 = (long long)((p.M + 255) / 256) * (pn.coutPad / 256);
             tile = b256 < h->tune.plan_cus * 3 / 4 ? TILE_128x128_FP8 : TILE_256x256_FP8;
+            // (latency-bound launches - at most two 128 x 128 tiles per CU, e.g. R101-700 at batch 8 - on 64 x 64 tiles:
+            // a K step of 128 costs a wave 4 MFMAs instead of 16 and four times as many workgroups share the CUs)
+            const long long b128 = (long long)((p.M + 127) / 128) * (pn.coutPad / 128);
+            if (tile == TILE_128x128_FP8 && o.nlev == 0 && h->tune.t64 && b128 <= 2ll * h->tune.plan_cus) tile = TILE_64x64_FP8;
         }
     }
     if (tile_out) *tile_out = tile;
