@@ -443,6 +443,46 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, ba
     return r
 
 
+def fp8_vs_oracles(seed, frame_u8, eng_out, fp8_layers, backbone, nthreads):
+    """configs[4]: the fp8 engine's detections on one frame against (a) the oracle's fp8 forward mode with the engine's own
+    calibrated scales - its checker - and (b) the f16 oracle - the price of the precision. The checker, never
+    the product."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    net = O.Net(backbone, frame_u8.shape[1], 81, seed=seed)
+    pri = net.priors()
+    out = {}
+    t0 = time.perf_counter()
+    h16 = net.forward(frame_u8[:1], f16=True, nthreads=nthreads)
+    out["oracle_f16_forward_s"] = round(time.perf_counter() - t0, 2)
+    out["engine_fp8_vs_oracle_f16"] = accuracy_vs_oracle(eng_out, O.detect(h16[0][0], h16[1][0], h16[2][0], h16[3][0], pri))
+    lay = {}
+    for name, sc in fp8_layers:
+        for nm in ([f"{name}{l}" for l in range(5)] if name in ("head_t", "head_out") else [name]):
+            lay[nm] = sc
+    net.set_fp8(lay)
+    h8 = net.forward(frame_u8[:1], f16=True, nthreads=nthreads)
+    net.set_fp8(None)
+    out["engine_vs_oracle_fp8_mode"] = accuracy_vs_oracle(eng_out, O.detect(h8[0][0], h8[1][0], h8[2][0], h8[3][0], pri))
+    out["engine_vs_oracle_fp8_mode"]["oracle_mode"] = f"fp8 forward mode, {len(fp8_layers)} E4M3 layers, the engine's calibrated scales"
+    return out
+
+
+def family_rooflines(prof):
+    """Every kernel symbol of a step with its own roofline figures (what bound it, achieved, share of the step)."""
+    _, by = dominant_kernel(prof)
+    total = sum(d["ms"] for d in by.values())
+    out = []
+    for sym, d in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
+        if d["flops"] <= 0 and d["bytes"] <= 0:
+            continue
+        tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        peak = MFMA_FP8_DENSE_PEAK_TFLOPS if sym.startswith("conv_igemm_fp8") else MFMA_F16_DENSE_PEAK_TFLOPS
+        out.append(dict(kernel=sym, launches=d["launches"], ms=round(d["ms"], 4), share_of_step=round(d["ms"] / total, 3),
+                        tflops=round(tf, 1), frac_mfma=round(tf / peak, 3), gbs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 3)))
+    return out
+
+
 VERBOSE = False
 
 
@@ -532,6 +572,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--no-batch1", action="store_true")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] sub-record (YOLACT-700 R101 fp8 at this rank's share of 64 frames over 8 GPUs)")
+    ap.add_argument("--configs4-batch", type=int, default=8, help="frames per GPU of the configs[4] sub-record (64 frames / 8 GPUs)")
     ap.add_argument("--verbose", action="store_true", help="phase markers on stderr")
     ap.add_argument("--tune", default="", help="comma-separated yh_tuning fields for A/B measurements, e.g. tailfork=1,k1tile=0 (default: none)")
     ap.add_argument("--torch-broadcast", action="store_true",
@@ -583,6 +625,31 @@ def main():
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
                                    latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"],
                                    host_to_detections_latency=aux1.get("host_to_detections_latency"))
+    if a.batch != 1 and not a.no_configs4 and not (a.backbone == 101 and a.precision == "fp8"):
+        # BASELINE.json configs[4]: YOLACT-700 ResNet-101, fp8 operands on the fp8 MFMA, batch 64 across 8 GPUs = 8 frames per
+        # GPU - this rank's share, timed in the same run (same contract: resident frames, graph replay, max over ranks)
+        src4 = ya.Engine(input_size=700, backbone=101, max_batch=1, use_graph=False, device=local_rank)
+        how4 = replicate_weights(ya, torch, dist, rank, world, local_rank, src4, a.seed, use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast))
+        s4 = max(a.steps, 20)
+        dt4, prof4, flops4, _, aux4 = run_config(ya, torch, dist, rank, world, local_rank, a.configs4_batch, s4, max(a.warmup, 3), a.seed, 700,
+                                                  src4.weights_device_ptr(), src4.weights_nbytes(), backbone=101, precision="fp8", tune=tune)
+        src4.close()
+        if rank == 0:
+            fps4 = world * a.configs4_batch * s4 / dt4
+            rec = dict(workload=f"YOLACT-700 R101-FPN fp8 (E4M3 operands on the {len(aux4['fp8_layers'])} K-heavy 3x3 launches, f16 elsewhere), "
+                                f"batch={a.configs4_batch} per GPU (configs[4]: 64 frames over 8 GPUs), 700x700x3 uint8 frames resident in HBM, hipGraph steady state",
+                       value=round(fps4, 2), unit="frames/s", n_gpus=world, steps=s4, ms_per_step=round(dt4 / s4 * 1e3, 4), dtype="fp8",
+                       net_tflops=round(fps4 * flops4 / 1e12, 2), gflop_per_frame=round(flops4 / 1e9, 2), weights_replication=how4,
+                       roofline=roofline_of(prof4, a.configs4_batch), kernel_families=family_rooflines(prof4), latency=aux4["latency"],
+                       pcie_inclusive_fps=aux4["pcie_inclusive_fps"])
+            fp8f = [k for k in rec["kernel_families"] if k["kernel"].startswith("conv_igemm_fp8")]
+            if fp8f:   # the fp8 launches as one family, against the 5 PFLOP/s dense fp8 peak
+                ms = sum(k["ms"] for k in fp8f); fl = sum(k["tflops"] * k["ms"] for k in fp8f)
+                rec["fp8_launches"] = dict(launches=sum(k["launches"] for k in fp8f), ms=round(ms, 4), tflops=round(fl / ms, 1),
+                                           peak=MFMA_FP8_DENSE_PEAK_TFLOPS, frac=round(fl / ms / MFMA_FP8_DENSE_PEAK_TFLOPS, 4))
+            if world == 1 and not a.no_cpu_baseline:
+                rec["accuracy"] = fp8_vs_oracles(a.seed, aux4["host_frame"], aux4["dets_frame0"], aux4["fp8_layers"], 101, usable_cores())
+            extra["configs4"] = rec
     src.close()
     if rank != 0:
         if dist is not None:
@@ -595,7 +662,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": f"YOLACT-{a.size} R{a.backbone}-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, "
-                               f"hipGraph steady state, frames sharded over {world} GPU(s), weights replicated by one RCCL broadcast",
+                               f"hipGraph steady state, frames sharded over {world} GPU(s), " + ("one GPU: no collective" if world == 1 else f"weights replicated once: {how}"),
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [a.size, a.size, 3],
                    "weights": f"seeded synthetic (seed {a.seed}), BN folded", "weights_replication": how,
                    "detections_first_frames": ndet},

@@ -153,7 +153,8 @@ const char* yh_version(void);
 /* Fills *cfg with the YOLACT-550 R50 defaults (every tuning field -1). */
 void yh_default_config(yh_config* cfg);
 /* Replaces the run-time tuning fields of a live handle (captured graphs are dropped and re-captured on the next
- * call); YH_ESTATE if a creation-time field (bigk, stemfuse, prefuse, headmerge, upfuse) differs from the handle's. */
+ * call); YH_ESTATE if a creation-time field (bigk, stemfuse, prefuse, headmerge, upfuse, dsfuse, protofuse) differs from
+ * the handle's. */
 int yh_set_tuning(yh_engine* h, const yh_tuning* tune);
 /* The handle's tuning with every default resolved (plan_cus = the CU count the plans really use, ...). */
 int yh_get_tuning(const yh_engine* h, yh_tuning* out);
@@ -186,12 +187,18 @@ int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
  * The K-heavy 3x3 convolutions read OCP E4M3 operands on the block-scaled fp8 MFMA: weights with one scale per
  * output channel (fixed when the weights are loaded), activations with one scale per tensor, which must be set
  * before the first invoke - by calibration on representative frames, or layer by layer from stored values. */
-/* Runs the f16 forward of the frames last set and sets every fp8 input tensor's scale to max|x| / 448. */
+/* Runs the f16 forward of the frames last set and sets every fp8 input tensor's scale to max|x| / 448. YH_ESTATE (and
+ * no scale changed) if that forward overflowed: a non-finite maximum would make every code of the tensor 0. */
 int yh_fp8_calibrate(yh_engine* h);
 /* The convolutions that read E4M3 operands, in execution order: layer name (DESIGN.md layer names: "l3b0_b", "p5",
  * "proto0", "head_t" ...) and the activation scale of its input tensor. */
 int yh_fp8_layer_count(const yh_engine* h);
 int yh_fp8_layer_info(const yh_engine* h, int32_t i, const char** conv_name, float* act_scale);
+/* Scales belong to TENSORS (allocations), not to layers: layers that read one allocation share theirs - P3..P7 live in one
+ * pyramid buffer, so setting the scale of "p6" also sets it for "p7", "head_t" and "proto0" (yh_fp8_layer_info shows it).
+ * A positive finite value is required. yh_invoke / yh_evaluate return YH_ESTATE, naming the layers, until EVERY E4M3
+ * input tensor has a scale (by calibration or by this call). Loading weights AGAIN on a handle discards the scales (they
+ * were calibrated for the old weights); scales set before the first load are kept. */
 int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale);
 
 /* ---- multi-GPU: the path's one collective (north_star: "weights replicated once via RCCL
@@ -326,7 +333,8 @@ int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** ou
 void yh_scene_destroy(yh_scene* h);
 const char* yh_scene_last_error(const yh_scene* h);
 /* One frame: depth u16 [h][w] (the R16_UINT texture, scene.rs:197) and the class image [h][w][2] = (class, id) (the
- * R8G8_UINT texture, scene.rs:198), both in host memory. Asynchronous on the handle's stream. */
+ * R8G8_UINT texture, scene.rs:198), both in host memory; the buffers are free again on return (pageable or pinned).
+ * The computation is asynchronous on the handle's stream. */
 int yh_scene_append(yh_scene* h, const uint16_t* depth_host, const uint8_t* class_id_host, int32_t compat_mode);
 /* The class image taken straight from a classified frame as yh_classify_frame_u32 leaves it (packed u32 [h][w];
  * frame_on_device = 1: a device pointer, e.g. yh_classify_device_frame - no host round trip of the class image).
@@ -336,7 +344,9 @@ int yh_scene_append_classified(yh_scene* h, const uint16_t* depth_host, const ui
 /* scene.rs:284-330: height map u32 [h][w], world / connections0 / connections1 f32 [h][w][4], balls f32 [100][4]
  * = (mean x, mean y, pixel count, 0). Any pointer may be NULL. Waits for the frame. */
 int yh_scene_read(yh_scene* h, uint32_t* map, float* world, float* conn0, float* conn1, float* balls);
-/* Measurement hook: mean device milliseconds per frame over `reps` re-runs of the last appended frame. */
+/* Measurement hook: mean device milliseconds per frame over `reps` re-runs of the last appended frame, with the inputs and
+ * the compat mode of that append (a device frame given to yh_scene_append_classified must still be valid). The re-runs
+ * overwrite the outputs with the same values. */
 int yh_scene_time(yh_scene* h, int32_t reps, float* ms_per_frame);
 /* Device copy of the frame the last yh_classify_frame_u32 produced (valid until the next classify on this handle). */
 const uint32_t* yh_classify_device_frame(const yh_engine* h);
@@ -389,11 +399,11 @@ int yh_op_stem_pool_f16(yh_engine* h, const uint16_t* x, int32_t n, int32_t S, c
  * ((v - mean) / std per channel, rounded to f16), as in production runs. */
 int yh_op_stem_pool_rgb8(yh_engine* h, const uint8_t* rgb, int32_t n, int32_t S, const uint16_t* w, const float* bias,
                          uint16_t* stem_out, uint16_t* pool_out);
-/* Groundwork for an fp8 convolution path (not used by the forward yet): y[i] = OCP FP8 E4M3 code of
+/* The quantiser of the fp8 forward (the producers' epilogues apply the same conversion): y[i] = OCP FP8 E4M3 code of
  * x[i] * inv_scale (x: f16 bits), round to nearest even, saturating at +-448, NaN -> 0x7F | sign. */
 int yh_op_quantize_e4m3(yh_engine* h, const uint16_t* x, size_t n, float inv_scale, uint8_t* y);
-/* Experimental fp8 convolution (not used by the forward yet): x[n][hh][ww][cin] and w[cout][k][k][cin] are E4M3
- * codes (cin % 128 == 0), f32 accumulation on the block-scaled MFMA with unit block scales,
+/* One fp8 convolution on the 256 x 256 tile the YH_PRECISION_FP8 forward uses: x[n][hh][ww][cin] and w[cout][k][k][cin]
+ * are E4M3 codes (cin % 128 == 0), f32 accumulation on the block-scaled MFMA with unit block scales,
  * y = act(acc * scale[ch] + bias[ch] + residual) rounded to f16. If reps > 0, *ms_per_launch receives the mean
  * kernel time of `reps` further launches. */
 int yh_op_conv2d_fp8(yh_engine* h, const uint8_t* x, int32_t n, int32_t hh, int32_t ww, int32_t cin, const uint8_t* w,

@@ -99,6 +99,10 @@ int orc_detect(const orc_det_cfg* cfg, const float* loc, const float* conf, cons
 /* ---- OCP FP8 E4M3 (orc_fp8.c): groundwork for an fp8 convolution path, pinned by exhaustive search ---- */
 /* accuracy study: the net's K-heavy 3x3 convs (cin >= 256) with E4M3-rounded operands (orc_net.c) */
 void orc_net_set_fp8_study(orc_net* net, int on);
+/* extended study: act_mode 0 off | 1 one scale per tensor | 2 E8M0 blocks of 32 channels | 3 one scale
+ * per input channel; w_mode 1 one scale per output channel | 2 E8M0 blocks of 32 along K; skip_csv: name prefixes kept f16.
+ * Applies to the convolutions the engine's fp8 plan takes (3x3, cin >= 256 and % 128 == 0, cout % 256 == 0). */
+void orc_net_set_fp8_study_ex(orc_net* net, int act_mode, int w_mode, const char* skip_csv);
 /* fp8 forward mode (configs[4]): name the convolutions that read E4M3 operands, each with its activation scale */
 void orc_net_clear_fp8(orc_net* net);
 int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale);

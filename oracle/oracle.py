@@ -223,6 +223,14 @@ class Net:
         for name, scale in (layers or {}).items():
             assert L.orc_net_add_fp8_layer(self.h, name.encode(), float(scale)) == 0, name
 
+    def set_fp8_study_ex(self, act_mode=0, w_mode=1, skip=""):
+        """Extended accuracy study (DESIGN.md §10): act_mode 0 off, 1 per tensor, 2 E8M0 blocks of 32, 3 per input channel;
+        w_mode 1 per output channel, 2 E8M0 blocks of 32; skip: comma-separated conv-name prefixes kept in f16."""
+        L = lib()
+        L.orc_net_set_fp8_study_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.orc_net_set_fp8_study_ex.restype = None
+        L.orc_net_set_fp8_study_ex(self.h, int(act_mode), int(w_mode), skip.encode())
+
     def forward(self, rgb, f16=True, nthreads=None, fp8_study=False):
         """fp8_study: the K-heavy 3x3 convs run on E4M3-rounded operands (accuracy study)."""
         lib().orc_net_set_fp8_study.argtypes = [C.c_void_p, C.c_int]

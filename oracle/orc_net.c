@@ -75,6 +75,9 @@ struct orc_net {
     double flops;
     int nthreads, f16;
     int fp8;   /* accuracy study: fake-quantise the K-heavy 3x3 convs' operands to E4M3 */
+    /* ... its extended form (orc_net_set_fp8_study_ex): how activations / weights are scaled, and which convolutions stay f16 */
+    int fp8_act_mode, fp8_w_mode;
+    char fp8_skip[256];   /* comma-separated name prefixes kept in f16 ("head_t,proto3") */
     /* fp8 forward mode (DESIGN.md §Precision, configs[4]): the named convolutions read E4M3 operands - activations with
      * the GIVEN per-tensor scale (the engine's calibration result), weights with one scale per output channel */
     int n_fp8;
@@ -357,6 +360,71 @@ static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x
             free(xq); free(wq); free(chs);
             return y;
         }
+    /* extended study (orc_net_set_fp8_study_ex): activations 1 per tensor | 2 MX blocks of 32 channels (E8M0) | 3 one scale
+     * per input channel (folded into the weights before their own per-output-channel quantisation); weights 1 per output
+     * channel | 2 MX blocks of 32 along K; convolutions whose name starts with an entry of the skip list stay f16. */
+    if (net->fp8_act_mode && cw->kh == 3 && cw->cin % 128 == 0 && cw->cin >= 256 && cw->cout % 256 == 0) {
+        int skip = 0;
+        for (const char* q = net->fp8_skip; *q;) {
+            const char* e = strchr(q, ',');
+            size_t len = e ? (size_t)(e - q) : strlen(q);
+            if (len && strncmp(name, q, len) == 0) skip = 1;
+            q += len + (e ? 1 : 0);
+        }
+        if (!skip) {
+            size_t nx = (size_t)x->n * x->h * x->w * x->c, K = (size_t)cw->kh * cw->kw * cw->cin, npx = nx / x->c;
+            float* xq = (float*)malloc(nx * sizeof(float));
+            float* wq = (float*)malloc(K * cw->cout * sizeof(float));
+            float* sc = (float*)malloc((size_t)x->c * sizeof(float));   /* per input channel (mode 3), else 1 */
+            for (int c = 0; c < x->c; ++c) sc[c] = 1.0f;
+            if (net->fp8_act_mode == 2) {
+                for (size_t i0 = 0; i0 < nx; i0 += 32) {
+                    float a = 0.0f;
+                    for (int e = 0; e < 32; ++e) { float v = fabsf(x->d[i0 + e]); if (v > a) a = v; }
+                    const float sb = a > 0.0f ? exp2f(ceilf(log2f(a / 448.0f))) : 1.0f;
+                    for (int e = 0; e < 32; ++e) xq[i0 + e] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i0 + e] / sb)) * sb;
+                }
+            } else if (net->fp8_act_mode == 3) {
+                for (int c = 0; c < x->c; ++c) sc[c] = 0.0f;
+                for (size_t i = 0; i < npx; ++i)
+                    for (int c = 0; c < x->c; ++c) { float a = fabsf(x->d[i * x->c + c]); if (a > sc[c]) sc[c] = a; }
+                for (int c = 0; c < x->c; ++c) sc[c] = sc[c] > 0.0f ? sc[c] / 448.0f : 1.0f;
+                for (size_t i = 0; i < npx; ++i)
+                    for (int c = 0; c < x->c; ++c) xq[i * x->c + c] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i * x->c + c] / sc[c])) * sc[c];
+            } else {
+                float ax = 0.0f;
+                for (size_t i = 0; i < nx; ++i) { float a = fabsf(x->d[i]); if (a > ax) ax = a; }
+                const float sx = ax > 0.0f ? ax / 448.0f : 1.0f;
+                for (size_t i = 0; i < nx; ++i) xq[i] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i] / sx)) * sx;
+            }
+            /* weights: w' = w * sc[c] is what gets quantised (mode 3 folds the activation's channel scale in); the value used is w'q / sc[c] */
+            for (int o = 0; o < cw->cout; ++o) {
+                if (net->fp8_w_mode == 2) {
+                    for (size_t k0 = 0; k0 < K; k0 += 32) {
+                        float a = 0.0f;
+                        for (int e = 0; e < 32; ++e) { float v = fabsf(cw->wt[(k0 + e) * cw->cout + o] * sc[(k0 + e) % x->c]); if (v > a) a = v; }
+                        const float sb = a > 0.0f ? exp2f(ceilf(log2f(a / 448.0f))) : 1.0f;
+                        for (int e = 0; e < 32; ++e) {
+                            const float s1 = sc[(k0 + e) % x->c];
+                            wq[(k0 + e) * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[(k0 + e) * cw->cout + o] * s1 / sb)) * sb / s1;
+                        }
+                    }
+                } else {
+                    float aw = 0.0f;
+                    for (size_t k = 0; k < K; ++k) { float a = fabsf(cw->wt[k * cw->cout + o] * sc[k % x->c]); if (a > aw) aw = a; }
+                    const float sw = aw > 0.0f ? aw / 448.0f : 1.0f;
+                    for (size_t k = 0; k < K; ++k) {
+                        const float s1 = sc[k % x->c];
+                        wq[k * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[k * cw->cout + o] * s1 / sw)) * sw / s1;
+                    }
+                }
+            }
+            conv_core(xq, x->n, x->h, x->w, x->c, wq, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
+                      res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo, NULL);
+            free(xq); free(wq); free(sc);
+            return y;
+        }
+    }
     /* study modes: 1 per-tensor / per-channel scales, 2 MX blocks, 3 = mode 1 on the protonet only */
     if (net->fp8 && cw->kh == 3 && cw->cin % 128 == 0 && cw->cin >= 256 && (net->fp8 != 3 || strncmp(name, "proto", 5) == 0)) {
         /* fp8 study: operands rounded to E4M3 - activations with one scale per tensor (max |x| -> 448),
@@ -477,6 +545,10 @@ void orc_net_destroy(orc_net* net) {
 }
 
 void orc_net_set_fp8_study(orc_net* net, int on) { net->fp8 = on; }
+void orc_net_set_fp8_study_ex(orc_net* net, int act_mode, int w_mode, const char* skip_csv) {
+    net->fp8_act_mode = act_mode; net->fp8_w_mode = w_mode;
+    snprintf(net->fp8_skip, sizeof net->fp8_skip, "%s", skip_csv ? skip_csv : "");
+}
 void orc_net_clear_fp8(orc_net* net) { net->n_fp8 = 0; }
 int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale) {
     if (net->n_fp8 >= 256 || !(act_scale > 0.0f)) return -1;

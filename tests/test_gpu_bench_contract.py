@@ -37,6 +37,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys(built):
     acc = cb["engine_vs_oracle_same_frame"]                       # a noise frame fills the list: ties at the top-k cut may swap
     assert acc["unmatched_oracle"] <= 3 and acc["unmatched_engine"] <= 3 and acc["unmatched_above_cut"] == 0 and acc["mask_iou_above_cut"] >= 0.99, acc
     assert b["batch1"]["value"] > 0
+    # BASELINE.json configs[4] in the same line: YOLACT-700 R101, fp8, this GPU's share (8 frames) of 64 frames over 8 GPUs
+    c4 = b["configs4"]
+    assert c4["value"] > 0 and c4["dtype"] == "fp8" and "R101" in c4["workload"] and abs(c4["value"] - 8 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) < 0.01 * c4["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c4["roofline"], k
+    assert c4["fp8_launches"]["launches"] == 36 and c4["fp8_launches"]["peak"] == 5000.0 and 0 < c4["fp8_launches"]["frac"] < 1
+    for k in ("engine_vs_oracle_fp8_mode", "engine_fp8_vs_oracle_f16"):
+        assert c4["accuracy"][k]["engine_dets"] > 0 and "matched_class_and_prior" in c4["accuracy"][k], k
 
 
 def test_graft_entry_smoke_runs(built):

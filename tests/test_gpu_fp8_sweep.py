@@ -1,0 +1,188 @@
+"""-m gpu: configs[4] layer by layer (BASELINE.json: YOLACT-700 ResNet-101, fp8 operands on the fp8 MFMA).
+
+Teacher-forced sweep of ALL 36 E4M3 launches at full geometry: each layer's input is the ENGINE's own tensor of that run
+(quantised by the same function its producer's epilogue applies), the oracle convolves the decoded operands in f32, and the
+engine's output of that one layer must agree within 2 f16 ulp + 2^-10 of the sum of |products| - the summation-order bound
+of tests/test_gpu_fp8.py, where only three layer kinds at 160 pixels were covered. Chained end to end, two fp8
+implementations drift apart by E4M3 code flips; teacher forcing removes exactly that and leaves the kernel.
+The reference's model is quantised end to end too (uint8: data/FRC_model_edgetpu.log:7-19); nothing in the reference pins
+E4M3 arithmetic: parity unpinned, engine == oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S7, NB = 700, 5   # batch 5: p3 / proto0-2 take the 128 x 128 fp8 tile, proto3 and the multi-level head trunk the 256 x 256 one, the rest 64 x 64
+
+
+def conv_indices(backbone):
+    """Layer name -> index in the canonical weight blob ("Weight blob")."""
+    idx, ci = {}, 1
+    for L, nb in enumerate((3, 4, 23, 3) if backbone == 101 else (3, 4, 6, 3)):
+        for b in range(nb):
+            idx[f"l{L + 1}b{b}_a"], idx[f"l{L + 1}b{b}_b"], idx[f"l{L + 1}b{b}_c"] = ci, ci + 1, ci + 2
+            ci += 4 if b == 0 else 3
+    for k, name in enumerate(("lat5", "lat4", "lat3", "p5", "p4", "p3", "p6", "p7", "proto0", "proto1", "proto2", "proto3", "proto", "head_t")):
+        idx[name] = ci + k
+    return idx
+
+
+def fp8_layer_table(backbone):
+    """(engine layer name, input tensor, output tensor, stride, relu) of every E4M3 launch but the multi-level head trunk."""
+    t = []
+    for L, nb in ((3, 23 if backbone == 101 else 6), (4, 3)):
+        for b in range(nb):
+            t.append((f"l{L}b{b}_b", f"l{L}b{b}_a", f"l{L}b{b}_b", 2 if b == 0 else 1, True))
+    t += [("p5", "lat5", "p5", 1, True), ("p6", "p5", "p6", 2, False), ("p7", "p6", "p7", 2, False), ("p4", "lat4", "p4", 1, True), ("p3", "lat3", "p3", 1, True),
+          ("proto0", "p3", "proto0", 1, True), ("proto1", "proto0", "proto1", 1, True), ("proto2", "proto1", "proto2", 1, True), ("proto3", "proto_up", "proto3", 1, True)]
+    return t
+
+
+class Forced:
+    """Teacher-forced expectation of one fp8 convolution from the engine's own input tensor."""
+
+    def __init__(self, oracle, blob, backbone):
+        import bench
+        self.O, self.convs, self.idx, self.table = oracle, bench.parse_blob(blob), conv_indices(backbone), oracle.e4m3_decode_table()
+        self._wq = {}
+
+    def weights(self, name):
+        if name not in self._wq:
+            w, b = self.convs[self.idx[name]]
+            aw = np.abs(w).reshape(w.shape[0], -1).max(1).astype(np.float32)
+            sw = np.where(aw > 0, aw / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+            inv = (np.float32(1.0) / sw).astype(np.float32)
+            wq = np.stack([self.table[self.O.quantize_e4m3(w[o], float(inv[o]))] for o in range(w.shape[0])]).astype(np.float32)
+            self._wq[name] = (wq, sw, b)
+        return self._wq[name]
+
+    def expect(self, name, x_f32, s_x, stride, relu):
+        """x_f32: the engine's input tensor [1][h][w][c] (f16 values, or exactly decoded E4M3 values). Returns (want f16-rounded,
+        sum of |products| in output units)."""
+        s_x = np.float32(s_x)
+        inv = float(np.float32(1.0) / s_x)                       # the epilogue multiplies by 1 / s (engine.hip: y8_inv_scale)
+        xq = self.table[self.O.quantize_e4m3(x_f32.astype(np.float32), inv)].astype(np.float32)
+        wq, sw, b = self.weights(name)
+        zero = np.zeros(wq.shape[0], np.float32)
+        acc = self.O.conv2d(xq, wq, zero, stride, 1, None, 0, f16=False)
+        mag = self.O.conv2d(np.abs(xq), np.abs(wq), zero, stride, 1, None, 0, f16=False) * (s_x * sw)
+        v = acc * (s_x * sw) + b
+        if relu:
+            v = np.maximum(v, 0)
+        return v.astype(np.float16).astype(np.float32), mag
+
+
+def _check(layer, got, want, mag, report):
+    ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
+    err = np.abs(got - want)
+    assert got.shape == want.shape, (layer, got.shape, want.shape)
+    ratio = float((err / np.maximum(mag, 1e-30)).max())
+    report.append(f"{layer}: max |err| {err.max():.5f}, {100 * (err > 2 * ulp).mean():.3f} % beyond 2 ulp, max err / sum|products| = 2^{np.log2(max(ratio, 1e-30)):.1f}")
+    bad = err > 2 * ulp + 2.0 ** -10 * mag + 1e-6
+    assert not bad.any(), (layer, int(bad.sum()), float(err.max()), ratio)
+
+
+@pytest.fixture(scope="module")
+def r101_fp8(built, oracle):
+    """The production engine P (every fusion on, E4M3-only tensors) and the same configuration with debug_tensors = 1 (D: every
+    tensor also in f16), both at batch 5 with P's calibrated scales."""
+    import yolact_amd as ya
+    P = ya.Engine(input_size=S7, backbone=101, max_batch=NB, use_graph=True, precision=ya.PRECISION_FP8)
+    blob = P.generate_weights(seed=1)
+    P.load_weights(blob)
+    frames = np.random.default_rng(17).integers(0, 256, (NB, S7, S7, 3), dtype=np.uint8)
+    P.set_input(frames)
+    P.fp8_calibrate()
+    P.evaluate()
+    D = ya.Engine(input_size=S7, backbone=101, max_batch=NB, use_graph=False, precision=ya.PRECISION_FP8, debug_tensors=True)
+    D.load_weights(blob)
+    assert [n for n, _ in D.fp8_layers()] == [n for n, _ in P.fp8_layers()]
+    for i, (_, sc) in enumerate(P.fp8_layers()):
+        D.fp8_set_layer_scale(i, sc)
+    D.set_input(frames)
+    D.evaluate()
+    yield P, D, blob, frames, Forced(oracle, blob, 101)
+    P.close(); D.close()
+
+
+def test_all_36_fp8_launches_teacher_forced_r101_700(r101_fp8):
+    P, D, blob, frames, forced = r101_fp8
+    sc = dict(D.fp8_layers())
+    assert len(sc) == 36
+    # which tile each launch took (yh_profile_run names): all three fp8 tiles and the multi-level 256 x 256 form are in the sweep
+    names = [p["name"] for p in D.profile(with_tail=False, reps=1)]
+    fp8_names = [n for n in names if n.startswith("conv_igemm_fp8<")]
+    assert len(fp8_names) == 36, fp8_names
+    tile_of = {n.split(":")[1].split("/")[0].split("+")[0]: n.split(":")[0] for n in fp8_names}
+    assert tile_of["proto3"] == "conv_igemm_fp8<256,256,2,4>" and tile_of["head_t"] == "conv_igemm_fp8<256,256,2,4>[ml]", tile_of
+    assert tile_of["p3"] == tile_of["proto1"] == "conv_igemm_fp8<128,128,2,2>", tile_of
+    assert tile_of["l3b7_b"] == tile_of["l4b1_b"] == tile_of["p6"] == "conv_igemm_fp8<64,64,2,2>", tile_of
+    report = []
+    for f in (0, NB - 1):                       # first and last frame of the batch: every tile row range is touched at both ends
+        for layer, xin, yout, stride, relu in fp8_layer_table(101):
+            if f and layer.startswith("l3b") and layer not in ("l3b0_b", "l3b11_b", "l3b22_b"):
+                continue                        # (the 23 identical layer-3 shapes: all on frame 0, three on the last frame)
+            want, mag = forced.expect(layer, D.tensor_frame(xin, f)[None], sc[layer], stride, relu)
+            _check(f"{layer}[frame {f}, {tile_of[layer]}]", D.tensor_frame(yout, f)[None], want, mag, report)
+        for l in range(5):                      # the shared head trunk: one multi-level launch, checked level by level
+            want, mag = forced.expect("head_t", D.tensor_frame(f"p{l + 3}", f)[None], sc["head_t"], 1, True)
+            _check(f"head_t{l}[frame {f}, {tile_of['head_t']}]", D.tensor_frame(f"head_t{l}", f)[None], want, mag, report)
+    print("\n".join(report))
+    # the multi-level 128 x 128 fp8 form (head trunk at batches below ~4): three frames on the same handles
+    D.set_input(frames[:3]); D.evaluate()
+    names3 = [p["name"] for p in D.profile(with_tail=False, reps=1)]
+    assert any(n.startswith("conv_igemm_fp8<128,128,2,2>[ml]:head_t") for n in names3), [n for n in names3 if "head_t" in n]
+    rep3 = []
+    for l in (0, 2, 4):
+        want, mag = forced.expect("head_t", D.tensor_frame(f"p{l + 3}", 2)[None], sc["head_t"], 1, True)
+        _check(f"head_t{l}[batch 3, frame 2, 128x128 ml]", D.tensor_frame(f"head_t{l}", 2)[None], want, mag, rep3)
+    print("\n".join(rep3))
+    D.set_input(frames); D.evaluate()
+
+
+def test_production_fp8_engine_e4m3_only_tensors_and_fused_prototype_conv(r101_fp8, oracle):
+    """The production plan (no debug tensors): tensors that only fp8 convolutions read exist ONLY as E4M3 codes, and the
+    largest conv runs on the 256 x 256 fp8 tile with the 1x1 prototype conv in its epilogue (proto3 is never written).
+    * E4M3-only outputs (p3..p7, proto0, proto1): the decoded engine tensor against the teacher-forced f16 expectation, which
+      the producer's epilogue then quantises - |difference| <= the summation bound + half an E4M3 step of the value (2^-4
+      relative; 2^-10 of the scale below the normal range) - and every decoded value is a code value times the scale.
+    * proto3 + proto fused: the prototypes against conv1x1(relu(teacher-forced proto3)) with the first conv's bound pushed
+      through the second conv's |weights|."""
+    import bench
+    import yolact_amd as ya
+    P, D, blob, frames, forced = r101_fp8
+    sc = dict(P.fp8_layers())
+    names = [p["name"] for p in P.profile(with_tail=False, reps=1)]
+    assert "conv_igemm_fp8<256,256,2,4>[+1x1]:proto3+proto" in names, [n for n in names if "proto" in n]
+    with pytest.raises(ya.YhError):
+        P.tensor_frame("proto3", 0)
+    consumer = {"p3": "proto0", "p4": "head_t", "p5": "p6", "p6": "p7", "p7": "head_t", "proto0": "proto1", "proto1": "proto2"}
+    codes = np.sort(forced.table[np.isfinite(forced.table)].astype(np.float64))
+    report = []
+    f = 1
+    for layer, xin, yout, stride, relu in fp8_layer_table(101):
+        if yout not in consumer:
+            continue
+        want, mag = forced.expect(layer, P.tensor_frame(xin, f)[None], sc[layer], stride, relu)
+        got = P.tensor_frame(yout, f)[None]
+        s_out = np.float32(sc[consumer[yout]])                     # the scale of the tensor this layer writes
+        q = got.astype(np.float64).ravel() / s_out                 # every decoded value is a code value times the scale
+        near = np.abs(codes[np.clip(np.searchsorted(codes, q), 1, len(codes) - 1)] - q)
+        near = np.minimum(near, np.abs(codes[np.clip(np.searchsorted(codes, q), 1, len(codes) - 1) - 1] - q))
+        assert (near <= 1e-5 * np.maximum(1.0, np.abs(q))).all(), layer
+        ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
+        half_step = np.maximum(np.abs(want) * 2.0 ** -4, s_out * 2.0 ** -10)
+        err = np.abs(got - np.clip(want, -448 * s_out, 448 * s_out))
+        report.append(f"{layer} (E4M3-only output): max |err| {err.max():.5f} vs half step {half_step.max():.5f}")
+        assert (err <= 2 * ulp + 2.0 ** -10 * mag + half_step * 1.001 + 1e-6).all(), (layer, float(err.max()))
+    # the fused pair
+    want3, mag3 = forced.expect("proto3", P.tensor_frame("proto_up", f)[None], sc["proto3"], 1, True)
+    w2, b2 = bench.parse_blob(blob)[forced.idx["proto"]]
+    want = np.maximum(oracle.conv2d(want3, w2, b2, 1, 0, None, 0, f16=False), 0).astype(np.float16).astype(np.float32)
+    tol3 = 2 * np.maximum(np.abs(want3), 2.0 ** -14) * 2.0 ** -10 + 2.0 ** -10 * mag3
+    push = oracle.conv2d(tol3, np.abs(w2), np.zeros_like(b2), 1, 0, None, 0, f16=False)
+    got = P.output(3)[f][None]
+    err = np.abs(got - want)
+    report.append(f"proto3+proto fused: max |err| {err.max():.5f}, bound max {float((push + 2 * np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10).max()):.5f}")
+    assert (err <= push + 2 * np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10 + 1e-6).all(), float(err.max())
+    print("\n".join(report))

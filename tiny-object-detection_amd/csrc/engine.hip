@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <set>
 #include <string>
@@ -149,6 +150,7 @@ struct yh_engine {
     std::set<std::string> fused_away;   // named tensors that production runs never write (debug_tensors = 1 materialises them)
     // fp8 precision (yh_config.precision): per-allocation activation scales, filled by yh_fp8_calibrate
     std::vector<float> act_scale;       // by Buf::sid
+    std::vector<char> scale_set;        // by Buf::sid: the scale was set by a calibration or by yh_fp8_set_layer_scale since the weights were loaded
     std::vector<half_t*> alloc_base;    // first element of allocation sid
     std::vector<long long> alloc_img;   // elements per image of allocation sid
     std::vector<int> fp8_ops;           // indices of the ops that read E4M3 operands
@@ -227,7 +229,7 @@ int new_buf(yh_engine* h, const char* name, int hh, int ww, int c, Buf* out) {
     b.d = (half_t*)p;
     b.zero = (half_t*)((char*)p + ((data_bytes + 15) & ~(size_t)15));
     b.sid = (int)h->act_scale.size();
-    h->act_scale.push_back(1.0f); h->alloc_base.push_back(b.d); h->alloc_img.push_back(b.img_stride);
+    h->act_scale.push_back(1.0f); h->scale_set.push_back(0); h->alloc_base.push_back(b.d); h->alloc_img.push_back(b.img_stride);
     if (h->cfg.precision == YH_PRECISION_FP8) {   // the E4M3 twin (288 GB of HBM: no aliasing games)
         const size_t qbytes = data_bytes / 2;
         rc = dev_alloc(h, &p, qbytes + 256);
@@ -1059,11 +1061,22 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     return YH_OK;
 }
 
+// fp8 precision: the E4M3 layers whose input tensor has no scale yet (comma-separated; empty = every tensor is set)
+std::string fp8_missing(const yh_engine* h) {
+    std::string out;
+    for (int oi : h->fp8_ops)
+        if (!h->scale_set[h->ops[oi].in.sid]) out += (out.empty() ? "" : ", ") + h->ops[oi].name;
+    return out;
+}
+
 int run(yh_engine* h, int with_tail) {
     if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no input set");
-    if (h->cfg.precision == YH_PRECISION_FP8 && !h->fp8_ready)
-        return h->fail(YH_ESTATE, "fp8 precision: the activation scales are not set - call yh_fp8_calibrate on representative frames first");
+    if (h->cfg.precision == YH_PRECISION_FP8 && !h->fp8_ready) {
+        const std::string miss = fp8_missing(h);
+        return h->fail(YH_ESTATE, "fp8 precision: the activation scales are not set - call yh_fp8_calibrate on representative frames (or yh_fp8_set_layer_scale for every layer) first" +
+                                  (miss.empty() ? std::string() : "; no scale yet for the input of: " + miss));
+    }
     HIPCHK(h, hipSetDevice(h->dev));
     const int n = h->cur_n;
     if (!h->cfg.use_graph) return enqueue_all(h, n, with_tail);
@@ -1201,6 +1214,14 @@ int upload_panels(yh_engine* h, const uint8_t* blob) {
             if (launch_quantize_rows_e4m3(p.w, p.w8, p.coutPad, p.Kpad, p.scale, h->stream) != hipSuccess) return h->fail(YH_EHIP, "weight quantisation launch failed");
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
+    }
+    if (h->weights_loaded && h->cfg.precision == YH_PRECISION_FP8) {
+        // a RE-load: the activation scales were calibrated for the old weights - they have to be set again (a first load
+        // keeps scales that were stored with the model and set beforehand)
+        std::fill(h->scale_set.begin(), h->scale_set.end(), 0);
+        h->fp8_ready = false; h->fp8_active = false;
+        for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
     }
     h->weights_loaded = true;
     if (h->fp8_ready) { const int rc = refresh_fp8_scales(h); if (rc) return rc; }
@@ -1387,9 +1408,12 @@ int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // the scales are baked into the captured launches
     h->graphs.clear();
-    h->act_scale[h->ops[h->fp8_ops[i]].in.sid] = act_scale;
-    // every layer has a scale (default 1.0 until set): the handle counts as calibrated once the caller has set them
-    h->fp8_ready = true; h->fp8_active = true;
+    const int sid = h->ops[h->fp8_ops[i]].in.sid;
+    h->act_scale[sid] = act_scale;
+    h->scale_set[sid] = 1;
+    // the handle counts as calibrated once EVERY E4M3 input tensor has a scale (scales are per tensor: layers that read
+    // one allocation - P3..P7 of the pyramid: p6, p7, head_t, proto0 - share theirs, include/yolact_hip.h)
+    h->fp8_ready = fp8_missing(h).empty(); h->fp8_active = h->fp8_ready;
     return h->weights_loaded ? refresh_fp8_scales(h) : YH_OK;
 }
 
@@ -1402,26 +1426,41 @@ int yh_fp8_calibrate(yh_engine* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     h->graphs.clear();
-    // 1. the f16 forward of these frames (every tensor in f16, as a YH_PRECISION_F16 handle computes it)
-    h->fp8_active = false;
-    int rc = enqueue_all(h, h->cur_n, 0);
-    if (rc) return rc;
-    // 2. one scale per tensor that an fp8 convolution reads: max |x| / 448 (E4M3's largest finite value)
+    // 1. the f16 forward of these frames (every tensor in f16, as a YH_PRECISION_F16 handle computes it); 2. one scale per
+    // tensor that an fp8 convolution reads: max |x| / 448 (E4M3's largest finite value). On any failure the handle keeps the
+    // scales (and the form of the forward) it had.
     std::set<int> sids;
     for (int oi : h->fp8_ops) sids.insert(h->ops[oi].in.sid);
     if (sids.size() > 64) return h->fail(YH_EINVAL, "too many fp8 input tensors");
-    HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, 256, h->stream));
-    int k = 0;
-    for (int sid : sids)
-        if (launch_absmax_f16(h->alloc_base[sid], (long long)h->cur_n * h->alloc_img[sid], h->absmax_dev + k++, h->stream) != hipSuccess)
-            return h->fail(YH_EHIP, "absmax launch failed");
     unsigned bits[64];
-    HIPCHK(h, hipMemcpyAsync(bits, h->absmax_dev, 256, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    k = 0;
+    h->fp8_active = false;
+    const int rc = [&]() -> int {
+        const int r = enqueue_all(h, h->cur_n, 0);
+        if (r) return r;
+        HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, 256, h->stream));
+        int k = 0;
+        for (int sid : sids)
+            if (launch_absmax_f16(h->alloc_base[sid], (long long)h->cur_n * h->alloc_img[sid], h->absmax_dev + k++, h->stream) != hipSuccess)
+                return h->fail(YH_EHIP, "absmax launch failed");
+        HIPCHK(h, hipMemcpyAsync(bits, h->absmax_dev, 256, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        k = 0;
+        for (int sid : sids) {   // (the maxima are combined as bit patterns of non-negative floats: Inf and every NaN compare above all finite values)
+            float a; memcpy(&a, &bits[k++], 4);
+            if (!(a < 3.0e38f)) {
+                std::string who;
+                for (int oi : h->fp8_ops) if (h->ops[oi].in.sid == sid) who += (who.empty() ? "" : ", ") + h->ops[oi].name;
+                return h->fail(YH_ESTATE, "fp8 calibration: the f16 forward of these frames overflowed (Inf / NaN) in the input tensor of " + who + "; no scale was changed");
+            }
+        }
+        return YH_OK;
+    }();
+    if (rc) { h->fp8_active = h->fp8_ready; return rc; }
+    int k = 0;
     for (int sid : sids) {
         float a; memcpy(&a, &bits[k++], 4);
         h->act_scale[sid] = a > 0.0f ? a / 448.0f : 1.0f;
+        h->scale_set[sid] = 1;
     }
     h->fp8_ready = true; h->fp8_active = true;
     return refresh_fp8_scales(h);

@@ -183,6 +183,7 @@ thread_local std::string g_scene_create_error;
 struct yh_scene {
     int dev = 0, W = 0, H = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t copied = nullptr;
     std::string err;
     uint16_t* depth = nullptr;
     uint8_t* cls_id = nullptr;
@@ -192,6 +193,10 @@ struct yh_scene {
     long long* ball_acc = nullptr;
     uint32_t *terrain_tab = nullptr, *robot_tab = nullptr;
     bool ran = false;
+    // what the last append ran on (yh_scene_time replays exactly this)
+    const uint8_t* last_cls = nullptr;
+    const uint32_t* last_frame = nullptr;
+    int last_frame_mode = 0, last_mode = 0;
     int fail(int code, const std::string& m) { err = m; return code; }
 };
 
@@ -215,6 +220,24 @@ int run_scene(yh_scene* h, const uint16_t* depth_dev, const uint8_t* cls_dev, co
     hipLaunchKernelGGL(scene_conn0, grid, block, 0, h->stream, p);
     SCHK(h, hipGetLastError());
     h->ran = true;
+    h->last_cls = cls_dev; h->last_frame = frame_dev; h->last_frame_mode = frame_mode; h->last_mode = mode;
+    return YH_OK;
+}
+
+// copy_from_slice semantics for host inputs (as yh_set_input_u8): the caller's buffers are free again when the call
+// returns. The runtime has staged a copy from PAGEABLE memory by then; from pinned / registered memory the DMA is still
+// reading, so wait for the copies (not for the kernels behind them: the event sits between the two).
+int host_sources_done(yh_scene* h, const void* a, const void* b) {
+    bool pinned = false;
+    for (const void* p : { a, b }) {
+        if (!p) continue;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) pinned = true;
+        else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
+    }
+    if (!pinned) return YH_OK;
+    SCHK(h, hipEventRecord(h->copied, h->stream));
+    SCHK(h, hipEventSynchronize(h->copied));
     return YH_OK;
 }
 }  // namespace
@@ -234,9 +257,14 @@ int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** ou
     const size_t npx = (size_t)width * height;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->copied, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&h->depth, npx * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&h->cls_id, npx * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&h->frame, npx * 4);
+    // (input images start defined: nothing the handle can be asked to run ever reads uninitialised device memory)
+    if (e == hipSuccess) e = hipMemsetAsync(h->depth, 0, npx * 2, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cls_id, 0, npx * 2, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->frame, 0, npx * 4, h->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&h->map, npx * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&h->world, npx * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&h->conn0, npx * 16);
@@ -261,6 +289,7 @@ void yh_scene_destroy(yh_scene* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     void* bufs[] = { h->depth, h->cls_id, h->frame, h->map, h->world, h->conn0, h->conn1, h->balls, h->ball_acc, h->terrain_tab, h->robot_tab };
     for (void* b : bufs) if (b) hipFree(b);
+    if (h->copied) hipEventDestroy(h->copied);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -272,6 +301,8 @@ int yh_scene_append(yh_scene* h, const uint16_t* depth_host, const uint8_t* clas
     const size_t npx = (size_t)h->W * h->H;
     SCHK(h, hipMemcpyAsync(h->depth, depth_host, npx * 2, hipMemcpyHostToDevice, h->stream));
     SCHK(h, hipMemcpyAsync(h->cls_id, class_id_host, npx * 2, hipMemcpyHostToDevice, h->stream));
+    const int rc = host_sources_done(h, depth_host, class_id_host);
+    if (rc) return rc;
     return run_scene(h, h->depth, h->cls_id, nullptr, 0, mode);
 }
 
@@ -283,6 +314,8 @@ int yh_scene_append_classified(yh_scene* h, const uint16_t* depth_host, const ui
     SCHK(h, hipMemcpyAsync(h->depth, depth_host, npx * 2, hipMemcpyHostToDevice, h->stream));
     const uint32_t* fdev = frame;
     if (!frame_on_device) { SCHK(h, hipMemcpyAsync(h->frame, frame, npx * 4, hipMemcpyHostToDevice, h->stream)); fdev = h->frame; }
+    const int rc = host_sources_done(h, depth_host, frame_on_device ? nullptr : frame);
+    if (rc) return rc;
     return run_scene(h, h->depth, nullptr, fdev, mode == YH_COMPAT_STRICT ? 0 : 1, mode);
 }
 
@@ -307,7 +340,10 @@ int yh_scene_time(yh_scene* h, int32_t reps, float* ms_per_frame) {
     hipEvent_t a, b;
     SCHK(h, hipEventCreate(&a)); SCHK(h, hipEventCreate(&b));
     SCHK(h, hipEventRecord(a, h->stream));
-    for (int r = 0; r < reps; ++r) { const int rc = run_scene(h, h->depth, h->cls_id, nullptr, 0, YH_COMPAT_SANE); if (rc) return rc; }
+    // the last append's own inputs and mode (a frame appended through yh_scene_append_classified is replayed from the
+    // frame it was given - a device frame must still be valid -, not from the class image buffer it never wrote)
+    const uint8_t* cls = h->last_cls; const uint32_t* fr = h->last_frame; const int fm = h->last_frame_mode, md = h->last_mode;
+    for (int r = 0; r < reps; ++r) { const int rc = run_scene(h, h->depth, cls, fr, fm, md); if (rc) { hipEventDestroy(a); hipEventDestroy(b); return rc; } }
     SCHK(h, hipEventRecord(b, h->stream));
     SCHK(h, hipEventSynchronize(b));
     float ms = 0;

@@ -552,17 +552,26 @@ int run_plan(yh_tfl* h) {
     if (!h->gexec) {
         hipGraph_t g = nullptr;
         TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-        {   // a second branch: the runtime then replays the graph node by node (see above)
-            TCHK(h, hipEventRecord(h->ev_fork, h->stream));
-            TCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            TCHK(h, hipMemsetAsync(h->side_word, 0, 4, h->side));
-            TCHK(h, hipEventRecord(h->ev_join, h->side));
-        }
-        const int rc = enqueue_plan(h);
-        if (!rc) TCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        // Inside the capture window nothing returns early: a failure is collected, the side stream is joined and the capture
+        // is ENDED in every case (a stream left capturing would fail every later call on the handle).
+        hipError_t ce = hipSuccess;
+        const char* where = "";
+        auto step = [&](hipError_t e, const char* what) { if (ce == hipSuccess && e != hipSuccess) { ce = e; where = what; } };
+        // a second branch: the runtime then replays the graph node by node (see above)
+        step(hipEventRecord(h->ev_fork, h->stream), "fork record");
+        step(hipStreamWaitEvent(h->side, h->ev_fork, 0), "fork wait");
+        step(hipMemsetAsync(h->side_word, 0, 4, h->side), "side memset");
+        step(hipEventRecord(h->ev_join, h->side), "join record");
+        const int rc = ce == hipSuccess ? enqueue_plan(h) : YH_OK;
+        step(hipStreamWaitEvent(h->stream, h->ev_join, 0), "join wait");   // (also after a failed enqueue: an unjoined fork invalidates the capture)
         const hipError_t e = hipStreamEndCapture(h->stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess || !g) return h->fail(YH_EHIP, std::string("tflite plan capture: ") + hipGetErrorString(e));
+        if (rc || ce != hipSuccess || e != hipSuccess || !g) {
+            if (g) hipGraphDestroy(g);
+            (void)hipGetLastError();
+            if (rc) return rc;   // (enqueue_plan has set the message)
+            return h->fail(YH_EHIP, ce != hipSuccess ? std::string("tflite plan capture (") + where + "): " + hipGetErrorString(ce)
+                                                     : std::string("tflite plan capture: ") + hipGetErrorString(e));
+        }
         const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (ei != hipSuccess) { h->gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
