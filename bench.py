@@ -558,6 +558,63 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
     return dt, prof, flops, ndet, aux
 
 
+def single_process_main(a, ya, torch, tune):
+    """--single-process: the sharded path as ONE process drives it through the library's own group API (yh_group_*: one host
+    worker thread + stream per device, contiguous frame blocks, one weight replication, no per-step collective) - what a
+    host that is not torch (the reference's Rust process, src/main.rs:63-75) would run. Same timing contract: resident
+    frames, W warm-up steps, exactly K timed steps between two syncs of every member, one JSON line."""
+    ndev = torch.cuda.device_count()
+    devices = list(range(a.gpus)) if ndev >= a.gpus else [0] * a.gpus
+    g = ya.Group(devices, input_size=a.size, backbone=a.backbone, max_batch=a.batch, use_graph=True,
+                 precision=ya.PRECISION_FP8 if a.precision == "fp8" else ya.PRECISION_F16, tune=tune)
+    blob = g.members[0].generate_weights(a.seed)
+    g.load_weights(blob)
+    ring = 2
+    bufs = []
+    for i, d in enumerate(devices):
+        gen = torch.Generator(device=f"cuda:{d}")
+        gen.manual_seed(0x594F4C41 + i * a.batch)
+        bufs.append([torch.randint(0, 256, (a.batch, a.size, a.size, 3), dtype=torch.uint8, device=f"cuda:{d}", generator=gen) for _ in range(ring)])
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    counts = [a.batch] * a.gpus
+    if a.precision == "fp8":
+        g.members[0].set_input_device(bufs[0][0].data_ptr(), a.batch)
+        g.fp8_calibrate()
+
+    def step(k):
+        g.evaluate_device([b[k % ring].data_ptr() for b in bufs], counts)
+    for k in range(a.warmup):
+        step(k)
+    g.sync()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(k)
+    g.sync()
+    dt = time.perf_counter() - t0
+    ndet = sum(len(g.detections(f, want_masks=False)[0]) for f in range(min(4, a.gpus * a.batch)))
+    e0 = g.members[0]
+    e0.n = a.batch
+    prof = e0.profile(with_tail=True, reps=3)
+    flops = e0.flops_per_frame()
+    fps = a.gpus * a.batch * a.steps / dt
+    line = {
+        "metric": f"frames/sec YOLACT-{a.size} (ResNet-{a.backbone}-FPN, 32 prototypes) " + ("fp16" if a.precision == "f16" else "fp8") + ", forward + detection tail",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": f"YOLACT-{a.size} R{a.backbone}-FPN batch={a.batch} per GPU, {a.size}x{a.size}x3 uint8 frames resident in HBM, hipGraph steady state, "
+                               f"ONE process: yh_group over devices {devices}" + (" (members share device 0: a rehearsal, not a measurement)" if ndev < a.gpus else ""),
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * a.gpus, "input": [a.size, a.size, 3],
+                   "weights": f"seeded synthetic (seed {a.seed}), BN folded", "weights_replication": g.weights_replication(),
+                   "detections_first_frames": ndet, "host": "single process, one worker thread per device (yh_group_evaluate_device)"},
+        "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
+        "roofline": roofline_of(prof, a.batch),
+    }
+    g.close()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -578,6 +635,9 @@ def main():
     ap.add_argument("--tune", default="", help="comma-separated yh_tuning fields for A/B measurements, e.g. tailfork=1,k1tile=0 (default: none)")
     ap.add_argument("--torch-broadcast", action="store_true",
                     help="replicate the weights with torch.distributed.broadcast instead of the library's own RCCL broadcast (yh_rank_broadcast_weights)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive --gpus N devices from ONE process through the library's group API (yh_group_*) instead of one rank per GPU; "
+                         "with fewer visible devices than N the members share device 0 (a rehearsal)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N > 1 path on a single-GPU box: every rank uses cuda:0 and the "
                          "weight broadcast goes over gloo (RCCL refuses two ranks on one device); not a measurement")
@@ -589,6 +649,10 @@ def main():
     import torch
     import yolact_amd as ya
     tune = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)} or None
+    if a.single_process:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP kernel library has no CPU fallback")
+        return single_process_main(a, ya, torch, tune)
     rank, world, local_rank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if a.rehearse_on_one_gpu:
         local_rank = 0

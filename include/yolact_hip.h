@@ -215,6 +215,40 @@ int yh_group_broadcast_weights(yh_engine** handles, int32_t n, int32_t root);
 int yh_rccl_unique_id(void* id_out /* YH_RCCL_ID_BYTES */);
 int yh_rank_broadcast_weights(yh_engine* h, const void* id, int32_t rank, int32_t nranks, int32_t root);
 
+/* ---- frame sharding over the GPUs of one node: one process, one engine handle per device,
+ * one host worker thread + stream per handle, contiguous frame blocks, no per-step collective. The reference's caller is
+ * ONE process that owns the frame loop (src/main.rs:63-75, src/scene.rs:77-92); this is what it calls with N frames to get
+ * N results over 8 devices. Two members may name the same device (they then share it: the form a one-GPU box can run). */
+typedef struct yh_group yh_group;
+/* cfg: the per-member configuration (cfg->device is ignored; cfg->max_batch = frames per member per step). */
+int yh_group_create(const yh_config* cfg, const int32_t* devices, int32_t n, yh_group** out);
+void yh_group_destroy(yh_group* g);
+const char* yh_group_last_error(const yh_group* g);   /* g may be NULL: last create error of this thread */
+int yh_group_size(const yh_group* g);
+/* Member i's own handle (weights on member 0, per-handle tuning, yh_debug_*, ...); owned by the group. */
+yh_engine* yh_group_member(yh_group* g, int32_t i);
+/* Loads the canonical blob on member 0 and replicates it: ONE RCCL broadcast over the distinct devices
+ * (yh_group_broadcast_weights), device-to-device copies for members that share a device with an earlier member, the host as
+ * the fallback when librccl cannot be used. yh_group_weights_replication says which of these ran. */
+int yh_group_load_weights_host(yh_group* g, const void* blob_host, size_t nbytes);
+/* The replication alone (member 0 already holds its weights, e.g. from yh_weights_generate + yh_load_weights_host). */
+int yh_group_replicate_weights(yh_group* g);
+const char* yh_group_weights_replication(const yh_group* g);
+/* fp8 precision: member 0 calibrates on the frames last set on it, every member runs with member 0's scales. */
+int yh_group_fp8_calibrate(yh_group* g);
+/* n_frames u8 RGB frames [n][S][S][3] in host memory, 1 <= n_frames <= members * max_batch: member i takes a contiguous block
+ * (the first n_frames % members members one frame more), copies it in underneath its previous step and enqueues
+ * yh_evaluate (with_tail = 1) or yh_invoke (0). Returns when every member has enqueued its step: the frames are free again,
+ * the GPUs run on; consecutive calls pipeline. */
+int yh_group_evaluate(yh_group* g, const uint8_t* frames_host, int32_t n_frames, int32_t with_tail);
+/* The same with frames resident on each member's own device: frames_dev[i] holds counts[i] frames (0: the member sits out). */
+int yh_group_evaluate_device(yh_group* g, const uint8_t* const* frames_dev, const int32_t* counts, int32_t with_tail);
+int yh_group_sync(yh_group* g);
+/* Results by GLOBAL frame index of the last yh_group_evaluate* (waits for that member's step): as yh_read_detections. */
+int yh_group_read_detections(yh_group* g, int32_t frame, int32_t* count, yh_detection* dets, int32_t dets_capacity, uint8_t* masks, size_t masks_capacity);
+/* Which member holds global frame `frame` of the last evaluate, and at which index of its batch. */
+int yh_group_frame_owner(const yh_group* g, int32_t frame, int32_t* member, int32_t* local);
+
 /* ---- interpreter-shaped surface (lets classify_tile, src/yolact.rs:133-190, port unchanged) -- */
 
 /* interpreter.inputs()[0] + tensor_info(..).dims (src/yolact.rs:149-150): {max_batch,S,S,3}. */
@@ -361,6 +395,12 @@ int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, fl
 /* Test hook: number of conv kernel launches the last yh_op_conv2d_f16 on this handle was planned as
  * (1 = single launch, 2 = two-phase or channel-split plan; the split-K reduce is not counted). */
 int yh_debug_last_conv_launches(const yh_engine* h);
+
+/* Audit hooks (profiles/r03_fault_audit.md). Text into out[cap] (YH_EOVERFLOW if truncated): every buffer of the handle
+ * with [base, end) and where those sit inside their 2 MiB page; the nodes of the step for the current batch size as the
+ * handle's tuning captures it (kernel symbol, grid, block, the pointers of its launch argument), sorted. */
+int yh_debug_alloc_map(yh_engine* h, char* out, size_t cap);
+int yh_debug_graph_nodes(yh_engine* h, int32_t with_tail, char* out, size_t cap);
 
 /* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */
 

@@ -100,10 +100,15 @@ static int conv_table(const orc_net_cfg* cfg, convspec* s) {
     int inc = 64;
     for (int L = 0; L < 4; ++L) {
         int planes = 64 << L;
+        /* a block's last conv: gain 0.3 in stages of up to six blocks; a deeper stage (ResNet-101's 23) scales it by sqrt(6 / blocks)
+         * so that the residual stream grows over the stage as it does in ResNet-50 (with 0.3 the R101 features are 3.6 x larger, the
+         * class logits exceed the background bias and ~47 000 candidates per frame saturate the softmax: DESIGN.md §2) */
+        const int nb_stage = blocks_of(cfg->backbone, L);
+        const float g3 = nb_stage > 6 ? 0.3f * sqrtf(6.0f / (float)nb_stage) : 0.3f;
         for (int b = 0; b < blocks_of(cfg->backbone, L); ++b) {
             ADD(planes, inc, 1, 1.0f, 0);
             ADD(planes, planes, 3, 1.0f, 0);
-            ADD(planes * 4, planes, 1, 0.3f, 0);
+            ADD(planes * 4, planes, 1, g3, 0);
             if (b == 0) ADD(planes * 4, inc, 1, 1.0f, 0);
             inc = planes * 4;
         }

@@ -1,0 +1,176 @@
+"""-m gpu: frame sharding as a library feature (yh_group_*: SURVEY.md §7.1 step 7, §8e) and the copy / compute overlap of
+yh_set_input_* (two input buffers + a copy stream).
+
+The reference's caller is one process that owns the frame loop (/root/reference/src/main.rs:63-75, src/scene.rs:77-92); a
+group is what it calls with N frames to get N results over the GPUs of a node. On the one-GPU test box the members share
+device 0 (weights then travel by device-to-device copy instead of the RCCL broadcast, which needs distinct devices: that
+path is unverified on hardware until an 8-GPU node runs it). A frame's result depends only on its member's batch size, so
+every member must reproduce, bit for bit, what a single engine gives for the same block of frames."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "tiny-object-detection_amd", "lib", "yolact_demo")
+TH = 0.005
+
+
+def _single(ya, blob, S, max_batch, blocks, **kw):
+    """Reference results: ONE engine, one block of frames at a time, serially."""
+    e = ya.Engine(input_size=S, max_batch=max_batch, use_graph=True, conf_thresh=TH, **kw)
+    e.load_weights(blob)
+    out = []
+    for fr in blocks:
+        e.set_input(fr); e.evaluate()
+        out += [e.detections(f) for f in range(fr.shape[0])]
+    e.close()
+    return out
+
+
+def _same(a, b):
+    (da, ma), (db, mb) = a, b
+    return da == db and np.array_equal(ma, mb)
+
+
+@pytest.mark.parametrize("S,per", [(256, 4), (550, 4)])
+def test_group_of_two_members_on_one_device_equals_single_engine(built, S, per):
+    import yolact_amd as ya
+    g = ya.Group([0, 0], input_size=S, max_batch=per, conf_thresh=TH)
+    blob = g.members[0].generate_weights(seed=1)
+    g.load_weights(blob)
+    assert "device-to-device" in g.weights_replication(), g.weights_replication()
+    rng = np.random.default_rng(31)
+    frames = rng.integers(0, 256, (2 * per, S, S, 3), dtype=np.uint8)
+    # full blocks: member 0 <- frames[:per], member 1 <- frames[per:]
+    g.evaluate(frames)
+    got = [g.detections(f) for f in range(2 * per)]
+    want = _single(ya, blob, S, per, [frames[:per], frames[per:]])
+    assert sum(len(d) for d, _ in want) >= 2 * per
+    assert [g.frame_owner(f) for f in (0, per - 1, per, 2 * per - 1)] == [(0, 0), (0, per - 1), (1, 0), (1, per - 1)]
+    for f in range(2 * per):
+        assert _same(got[f], want[f]), f
+    # ragged: 2 * per - 1 frames -> blocks of per and per - 1; and a call that leaves member 1 idle
+    g.evaluate(frames[: 2 * per - 1])
+    want = _single(ya, blob, S, per, [frames[:per], frames[per: 2 * per - 1]])
+    for f in range(2 * per - 1):
+        assert _same(g.detections(f), want[f]), f
+    g.evaluate(frames[:1])
+    assert g.frame_owner(0) == (0, 0) and _same(g.detections(0), _single(ya, blob, S, per, [frames[:1]])[0])
+    with pytest.raises(ya.YhError):
+        g.detections(1)                                   # out of the last call's range
+    with pytest.raises(ya.YhError):
+        g.evaluate(np.zeros((2 * per + 1, S, S, 3), np.uint8))   # more than members * max_batch
+    # back-to-back calls pipeline (no sync in between): the last call's results are what is read
+    for k in range(3):
+        g.evaluate(np.roll(frames, k, axis=0))
+    want = _single(ya, blob, S, per, [np.roll(frames, 2, axis=0)[:per], np.roll(frames, 2, axis=0)[per:]])
+    for f in range(2 * per):
+        assert _same(g.detections(f), want[f]), f
+    g.close()
+
+
+def test_group_evaluate_device_with_resident_frames(built):
+    torch = pytest.importorskip("torch")
+    import yolact_amd as ya
+    S, per = 256, 3
+    g = ya.Group([0, 0, 0], input_size=S, max_batch=per, conf_thresh=TH)
+    blob = g.members[0].generate_weights(seed=1)
+    g.load_weights(blob)
+    gen = torch.Generator(device="cuda:0").manual_seed(7)
+    bufs = [torch.randint(0, 256, (per, S, S, 3), dtype=torch.uint8, device="cuda:0", generator=gen) for _ in range(3)]
+    torch.cuda.synchronize()
+    g.evaluate_device([b.data_ptr() for b in bufs], [3, 0, 2])           # member 1 sits out
+    got = [g.detections(f) for f in range(5)]
+    want = _single(ya, blob, S, per, [bufs[0].cpu().numpy(), bufs[2].cpu().numpy()[:2]])
+    assert g.frame_owner(3) == (2, 0)
+    for f in range(5):
+        assert _same(got[f], want[f]), f
+    g.close()
+
+
+def test_cpp_group_host_matches_python(built, tmp_path):
+    import yolact_amd as ya
+    S, per, n = 256, 3, 5
+    frames = np.random.default_rng(3).integers(0, 256, (n, S, S, 3), dtype=np.uint8)
+    fin, fout = tmp_path / "frames.u8", tmp_path / "dets.txt"
+    frames.tofile(fin)
+    r = subprocess.run([DEMO, "--group", str(fin), str(fout), str(n), str(S), str(per), "0,0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "2 members" in r.stdout and "device-to-device" in r.stdout
+    g = ya.Group([0, 0], input_size=S, max_batch=per)                    # default threshold, as the C++ host
+    blob = g.members[0].generate_weights(seed=1)
+    g.load_weights(blob)
+    g.evaluate(frames)
+    lines = []
+    for f in range(n):
+        for d in g.detections(f, want_masks=False)[0]:
+            bits = np.array([d["score"], *d["box"]], np.float32).view(np.uint32)
+            lines.append("%d %d %d %08x %08x %08x %08x %08x" % (f, d["class_id"], d["prior"], *bits))
+    g.close()
+    assert fout.read_text().split("\n")[:-1] == lines
+
+
+@pytest.mark.parametrize("n", [1, 8])
+def test_set_input_overlaps_the_running_step_and_changes_no_bit(built, n):
+    """yh_set_input_u8 of frame batch k+1 is issued while step k runs (its copy goes to the other input buffer on the copy
+    stream), the host buffer is overwritten as soon as the call returns (copy_from_slice semantics, src/yolact.rs:161-162),
+    and every step's heads, detections and masks equal the serial order bit for bit. n = 1: pinned staging path (<= 4 MB);
+    n = 8: the runtime's pageable path; plus a pinned (torch) source for both."""
+    import yolact_amd as ya
+    S, K = 550, 7
+    rng = np.random.default_rng(41 + n)
+    F = rng.integers(0, 256, (K, n, S, S, 3), dtype=np.uint8)
+    eng = ya.Engine(input_size=S, max_batch=n, use_graph=True)
+    blob = eng.generate_weights(seed=1)
+    eng.load_weights(blob)
+    want = []
+    for k in range(K):                                   # serial: copy, step, read
+        eng.set_input(F[k]); eng.evaluate()
+        want.append(([eng.output(i) for i in (1, 3)], [eng.detections(f) for f in range(n)]))
+
+    def read():
+        return [eng.output(i) for i in (1, 3)], [eng.detections(f) for f in range(n)]
+
+    def check(got):
+        for k in range(K):
+            for a, b in zip(got[k][0], want[k][0]):
+                assert np.array_equal(a, b), k
+            for a, b in zip(got[k][1], want[k][1]):
+                assert _same(a, b), k
+    sources = [np.empty((n, S, S, 3), np.uint8)]
+    try:
+        import torch
+        sources.append(torch.empty((n, S, S, 3), dtype=torch.uint8).pin_memory().numpy())
+    except Exception:   # noqa: BLE001 - no torch: the pageable source alone
+        pass
+    for buf in sources:
+        got = []
+        buf[:] = F[0]; eng.set_input(buf); buf[:] = 0xAB
+        eng.evaluate()
+        for k in range(1, K):
+            buf[:] = F[k]; eng.set_input(buf); buf[:] = 0xAB      # copy k runs under step k - 1; the source is reused at once
+            got.append(read())                                     # results of step k - 1 (the main stream is waited for)
+            eng.evaluate()
+        got.append(read())
+        check(got)
+    # steps that re-use the frames last set (no yh_set_input_* in between) read the same buffer again
+    eng.evaluate()
+    assert all(np.array_equal(a, b) for a, b in zip(read()[0], want[K - 1][0]))
+    eng.close()
+
+
+def test_bench_single_process_mode_prints_the_contract_line(built):
+    """bench.py --single-process: the N-GPU path driven by ONE process through yh_group_* (two members sharing device 0 here)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "3", "--warmup", "2", "--batch", "4"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["global_batch"] == 8 and b["scaling"] == "weak" and "yh_group" in b["config"]["workload"]
+    assert abs(b["value"] - 2 * 4 * 3 / (b["ms_per_step"] * 3e-3)) < 0.01 * b["value"] and b["roofline"]["frac"] > 0

@@ -23,6 +23,18 @@
 
 using namespace yh;
 
+namespace yh {
+const RoctxApi& roctx_api() {   // resolved once per process (C++11 static initialisation); see yh_internal.h
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        a.push = (int (*)(const char*))dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        a.pop = (int (*)())dlsym(RTLD_DEFAULT, "roctxRangePop");
+        return a;
+    }();
+    return api;
+}
+}  // namespace yh
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -146,6 +158,7 @@ struct yh_engine {
     std::vector<Panel> panels;
     std::vector<Op> ops;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;   // parallel to allocs (yh_debug_alloc_map)
     std::map<std::string, Buf> named;
     std::set<std::string> fused_away;   // named tensors that production runs never write (debug_tensors = 1 materialises them)
     // fp8 precision (yh_config.precision): per-allocation activation scales, filled by yh_fp8_calibrate
@@ -159,7 +172,16 @@ struct yh_engine {
     bool fp8_ready = false;             // scales calibrated
     unsigned* absmax_dev = nullptr;
 
-    uint8_t* in_u8 = nullptr;
+    // Two input buffers and a copy stream: yh_set_input_* fills the buffer the running step does NOT read, so frame k+1's
+    // host -> device copy runs underneath step k (the limiter of the sharded path is host-side H2D). A step is
+    // captured once per buffer (the stem kernel's source pointer is a launch argument).
+    uint8_t* in_buf[2] = { nullptr, nullptr };
+    int in_cur = 0;                 // the buffer the next step reads
+    bool in_pending = false;        // a copy into in_buf[in_cur] has been issued that no step has waited for yet
+    hipStream_t copy = nullptr;
+    hipEvent_t in_ready[2] = { nullptr, nullptr }, in_free[2] = { nullptr, nullptr };
+    bool in_free_rec[2] = { false, false };
+    uint8_t* in_u8() const { return in_buf[in_cur]; }
     int in_hp = 0;
     Buf in_f16, pyr, pyr_t, heads, proto;
     float* priors_dev = nullptr;
@@ -214,6 +236,7 @@ int dev_alloc(yh_engine* h, void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return h->fail(YH_ENOMEM, std::string("hipMalloc ") + std::to_string(bytes) + ": " + hipGetErrorString(e));
     h->allocs.push_back(*p);
+    h->alloc_bytes.push_back(bytes);
     return YH_OK;
 }
 
@@ -258,10 +281,14 @@ void build_conv_table(yh_engine* h) {
     int inc = 64;
     for (int L = 0; L < 4; ++L) {
         const int planes = 64 << L;
+        // a block's last conv: gain 0.3 in stages of up to six blocks; ResNet-101's 23-block stage scales it by sqrt(6 / blocks) so
+        // that the residual stream grows over the stage as it does in ResNet-50 (the same two f32 operations as the oracle)
+        const int nb_stage = blocks_of(h->cfg.backbone, L);
+        const float g3 = nb_stage > 6 ? 0.3f * sqrtf(6.0f / (float)nb_stage) : 0.3f;
         for (int b = 0; b < blocks_of(h->cfg.backbone, L); ++b) {
             add(planes, inc, 1, 1.0f, 0);
             add(planes, planes, 3, 1.0f, 0);
-            add(planes * 4, planes, 1, 0.3f, 0);
+            add(planes * 4, planes, 1, g3, 0);
             if (b == 0) add(planes * 4, inc, 1, 1.0f, 0);
             inc = planes * 4;
         }
@@ -344,8 +371,11 @@ int build_graph_spec(yh_engine* h) {
     (void)N;
     int rc;
     void* p = nullptr;
-    if ((rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * S * S * 3))) return rc;
-    h->in_u8 = (uint8_t*)p;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dev_alloc(h, &p, (size_t)h->cfg.max_batch * S * S * 3))) return rc;
+        h->in_buf[k] = (uint8_t*)p;
+        if (hipMemset(p, 0, (size_t)h->cfg.max_batch * S * S * 3) != hipSuccess) return h->fail(YH_EHIP, "hipMemset input");
+    }
     h->in_hp = S + 8;  // 3-pixel zero border + slack for the stem's 8th (zero-weight) tap column
     if ((rc = new_buf(h, "input", h->in_hp, h->in_hp, 4, &h->in_f16))) return rc;
 
@@ -952,7 +982,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
     if (side && o.kind != OP_CONV) return h->fail(YH_EINVAL, "only convolutions fork onto the side stream");
     switch (o.kind) {
         case OP_PRE:
-            e = launch_preprocess(h->in_u8, h->in_f16.d, n, h->S, h->in_hp, h->in_hp, h->stream);
+            e = launch_preprocess(h->in_u8(), h->in_f16.d, n, h->S, h->in_hp, h->in_hp, h->stream);
             break;
         case OP_CONV: {
             ConvParams p;
@@ -976,7 +1006,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
             const Panel& pn = h->panels[o.panel];
             StemPoolParams sp;
             sp.x = o.in.d; sp.w = pn.w; sp.bias = pn.bias; sp.pool = o.out.d;
-            sp.rgb = h->pre_fused ? h->in_u8 : nullptr; sp.S = h->S;
+            sp.rgb = h->pre_fused ? h->in_u8() : nullptr; sp.S = h->S;
             sp.stem = h->cfg.debug_tensors ? o.res.d : nullptr;
             sp.n = n; sp.Hp = o.in.h; sp.Wp = o.in.w; sp.SO = o.res.h; sp.PO = o.out.h;
             sp.tiles_y = (o.out.h + 7) / 8; sp.tiles_x = (o.out.w + 7) / 8;
@@ -1024,6 +1054,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     // order itself; the main stream waits for the side stream once, before the mask kernel (or at the end of the step).
     int n_forks = 0;
     bool prev_side = false, used_side = false;
+    TraceRange tr_fwd("yh:forward(enqueue)");
     auto fork_to_side = [&]() -> int {
         hipEvent_t ev = h->ev_forks[n_forks++ & 3];
         HIPCHK(h, hipEventRecord(ev, h->stream));
@@ -1052,6 +1083,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
     if (with_tail) {
+        TraceRange tr_tail("yh:tail(enqueue)");
         h->det.n = n;
         const hipError_t e = tail_forked ? launch_detect_stage(h->det, 4, h->stream)   // masks: need the prototypes too
                                          : launch_detect(h->det, h->stream);
@@ -1069,6 +1101,32 @@ std::string fp8_missing(const yh_engine* h) {
     return out;
 }
 
+// The step about to be enqueued on the main stream reads in_buf[in_cur]: if a copy into it is still pending on the copy
+// stream, the main stream waits for it (once per set_input).
+int wait_input(yh_engine* h) {
+    if (!h->in_pending) return YH_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->in_ready[h->in_cur], 0));
+    h->in_pending = false;
+    return YH_OK;
+}
+
+int capture_step(yh_engine* h, int n, int with_tail, hipGraphExec_t* out) {
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    h->capturing = true;
+    int rc = enqueue_all(h, n, with_tail);
+    h->capturing = false;
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    *out = ge;
+    return YH_OK;
+}
+
 int run(yh_engine* h, int with_tail) {
     if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no input set");
@@ -1078,24 +1136,26 @@ int run(yh_engine* h, int with_tail) {
                                   (miss.empty() ? std::string() : "; no scale yet for the input of: " + miss));
     }
     HIPCHK(h, hipSetDevice(h->dev));
+    TraceRange tr(with_tail ? "yh_evaluate" : "yh_invoke");
     const int n = h->cur_n;
+    int rc = wait_input(h);
+    if (rc) return rc;
     if (!h->cfg.use_graph) return enqueue_all(h, n, with_tail);
-    const int key = n * 2 + (with_tail ? 1 : 0);
+    const int key = (n * 2 + (with_tail ? 1 : 0)) * 2 + h->in_cur;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
-        hipGraph_t g = nullptr;
-        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-        h->capturing = true;
-        int rc = enqueue_all(h, n, with_tail);
-        h->capturing = false;
-        hipError_t e = hipStreamEndCapture(h->stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        hipGraphExec_t ge = nullptr;
-        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (e != hipSuccess) return h->fail(YH_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        it = h->graphs.emplace(key, ge).first;
+        // first step of this shape: capture it for BOTH input buffers now, so that the alternation of yh_set_input_* never
+        // puts a capture inside a timed region later
+        const int cur = h->in_cur;
+        for (int b = 0; b < 2 && rc == YH_OK; ++b) {
+            h->in_cur = b;
+            hipGraphExec_t ge = nullptr;
+            rc = capture_step(h, n, with_tail, &ge);
+            if (rc == YH_OK) h->graphs.emplace((key & ~1) | b, ge);
+        }
+        h->in_cur = cur;
+        if (rc) return rc;
+        it = h->graphs.find(key);
     }
     HIPCHK(h, hipGraphLaunch(it->second, h->stream));
     return YH_OK;
@@ -1301,6 +1361,11 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     hipError_t e = hipSetDevice(h->dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking);
+    for (int k = 0; k < 2; ++k) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->in_ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->in_free[k], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev0, hipEventDefault);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -1340,6 +1405,7 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
 void yh_destroy(yh_engine* h) {
     if (!h) return;
     hipSetDevice(h->dev);
+    if (h->copy) hipStreamSynchronize(h->copy);   // (a frame copy that no step consumed may still be in flight)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->side) hipStreamSynchronize(h->side);   // (every step joins the side stream into the main one; belt and braces before the frees)
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
@@ -1352,6 +1418,8 @@ void yh_destroy(yh_engine* h) {
     if (h->stitch_dev) hipFree(h->stitch_dev);
     if (h->diverged_dev) hipFree(h->diverged_dev);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->copy) hipStreamDestroy(h->copy);
+    for (int k = 0; k < 2; ++k) { if (h->in_ready[k]) hipEventDestroy(h->in_ready[k]); if (h->in_free[k]) hipEventDestroy(h->in_free[k]); }
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (hipEvent_t ev : h->ev_forks) if (ev) hipEventDestroy(ev);
     for (int k = 0; k < 2; ++k) { if (h->stage_ev[k]) hipEventDestroy(h->stage_ev[k]); if (h->stage[k]) hipHostFree(h->stage[k]); }
@@ -1435,7 +1503,9 @@ int yh_fp8_calibrate(yh_engine* h) {
     unsigned bits[64];
     h->fp8_active = false;
     const int rc = [&]() -> int {
-        const int r = enqueue_all(h, h->cur_n, 0);
+        int r = wait_input(h);
+        if (r) return r;
+        r = enqueue_all(h, h->cur_n, 0);
         if (r) return r;
         HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, 256, h->stream));
         int k = 0;
@@ -1659,37 +1729,46 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     if (!h || !src) return YH_EINVAL;
     if (n < 1 || n > h->cfg.max_batch) return h->fail(YH_EINVAL, "n_frames out of range");
     HIPCHK(h, hipSetDevice(h->dev));
+    TraceRange tr(kind == hipMemcpyHostToDevice ? "yh_set_input_u8" : "yh_set_input_u8_device");
     const size_t bytes = (size_t)n * h->S * h->S * 3;
-    // Small host inputs (a camera frame or two) go through a pinned double buffer: an async copy from
-    // PAGEABLE memory first drains the stream, so frame k+1's copy could not start before frame k's
-    // step had finished (0.49 of the resident rate at batch 1). The caller's buffer is free again on
-    // return either way. Large batches keep the runtime's own pageable path, which pipelines its chunks
-    // and beats a single-threaded memcpy into staging.
+    // The copy goes to the buffer the current step does NOT read, on the copy stream: it runs underneath the step that is
+    // executing (or queued) on the main stream. Ordering, by events only:
+    //   in_free[cur]  recorded on the main stream NOW = every step enqueued so far that reads the current buffer;
+    //   in_free[nb]   recorded one yh_set_input_* ago = the steps that read buffer nb: the copy waits for it;
+    //   in_ready[nb]  recorded behind the copy: the next step waits for it (run() -> wait_input).
+    const int cur = h->in_cur, nb = cur ^ 1;
+    HIPCHK(h, hipEventRecord(h->in_free[cur], h->stream));
+    h->in_free_rec[cur] = true;
+    if (h->in_free_rec[nb]) HIPCHK(h, hipStreamWaitEvent(h->copy, h->in_free[nb], 0));
+    uint8_t* dst = h->in_buf[nb];
+    // Small host inputs (a camera frame or two) go through a pinned double buffer: an async copy from PAGEABLE memory is
+    // staged by the runtime in a way that first drains the stream. Large batches keep the runtime's own pageable path, which
+    // pipelines its chunks and beats a single-threaded memcpy into staging. The caller's buffer is free again on return either way.
     if (kind == hipMemcpyHostToDevice && bytes <= yh_engine::kStageBytes) {
         const int k = h->stage_idx ^= 1;
         if (!h->stage[k]) {
             HIPCHK(h, hipHostMalloc((void**)&h->stage[k], yh_engine::kStageBytes, hipHostMallocDefault));
             HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
         } else {
-            HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this buffer has finished
+            HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this staging buffer has finished
         }
         memcpy(h->stage[k], src, bytes);
-        HIPCHK(h, hipMemcpyAsync(h->in_u8, h->stage[k], bytes, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipEventRecord(h->stage_ev[k], h->stream));
-        h->cur_n = n;
-        return YH_OK;
+        HIPCHK(h, hipMemcpyAsync(dst, h->stage[k], bytes, hipMemcpyHostToDevice, h->copy));
+        HIPCHK(h, hipEventRecord(h->stage_ev[k], h->copy));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(dst, src, bytes, kind, h->copy));
     }
-    HIPCHK(h, hipMemcpyAsync(h->in_u8, src, bytes, kind, h->stream));
-    if (kind == hipMemcpyHostToDevice) {
-        // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. The runtime
-        // stages an async copy from PAGEABLE memory before returning; from pinned / registered memory it is a true
-        // DMA that is still reading the buffer, so wait for it.
+    HIPCHK(h, hipEventRecord(h->in_ready[nb], h->copy));
+    if (kind == hipMemcpyHostToDevice && bytes > yh_engine::kStageBytes) {
+        // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. The runtime has staged an
+        // async copy from PAGEABLE memory before returning; from pinned / registered memory it is a true DMA that is still
+        // reading the buffer, so wait for it (for the copy only - the step underneath keeps running).
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
-            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(h, hipEventSynchronize(h->ev_fork));
-        } else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
+        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) HIPCHK(h, hipEventSynchronize(h->in_ready[nb]));
+        else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
     }
+    h->in_cur = nb;
+    h->in_pending = true;
     h->cur_n = n;
     return YH_OK;
 }
@@ -1730,6 +1809,7 @@ int yh_output_read_f32(yh_engine* h, int32_t index, float* dst, size_t nfloats) 
     if (!h || !dst || index < 0 || index > 4) return YH_EINVAL;
     if (h->cur_n < 1) return h->fail(YH_ESTATE, "no inference has run");
     HIPCHK(h, hipSetDevice(h->dev));
+    TraceRange tr("yh_output_read_f32");
     const int n = h->cur_n;
     size_t need = 0;
     switch (index) {
@@ -1767,6 +1847,7 @@ int yh_read_detections(yh_engine* h, int32_t frame, int32_t* count, yh_detection
     if (!h || !count) return YH_EINVAL;
     if (frame < 0 || frame >= h->cur_n) return h->fail(YH_EINVAL, "frame out of range");
     HIPCHK(h, hipSetDevice(h->dev));
+    TraceRange tr("yh_read_detections");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int nd = 0;
     HIPCHK(h, hipMemcpy(&nd, h->det.det_count + frame, 4, hipMemcpyDeviceToHost));
@@ -1886,10 +1967,13 @@ int yh_classify_frame_u32(yh_engine* h, uint32_t* frame, int32_t w, int32_t hh, 
     if ((rc = grow(h, (void**)&h->frame_dev, &h->frame_cap, npx * 4))) return rc;
     const size_t tmp_need = (size_t)3 * 4 * ((size_t)w * S > (size_t)2 * S * hh ? (size_t)w * S : (size_t)2 * S * hh);
     if ((rc = grow(h, (void**)&h->rs_tmp, &h->rs_tmp_cap, tmp_need))) return rc;
-    // yolact.rs:195-214: unpack, resize_exact(2S, S), crop two tiles -> engine input (batch of 2)
+    // yolact.rs:195-214: unpack, resize_exact(2S, S), crop two tiles -> engine input (batch of 2: written by the resize
+    // kernels into the current input buffer, behind whatever copy a yh_set_input_* may have left pending on it)
+    TraceRange tr("yh_classify_frame_u32");
+    if ((rc = wait_input(h))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->frame_dev, frame, npx * 4, hipMemcpyHostToDevice, h->stream));
     hipError_t e = launch_resize_v_u32(h->frame_dev, w, hh, h->rs_tmp, S, h->stream);
-    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->in_u8, 2 * S, 1, h->stream);
+    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->in_u8(), 2 * S, 1, h->stream);
     if (e != hipSuccess) return h->fail(YH_EHIP, std::string("classify pre: ") + hipGetErrorString(e));
     h->cur_n = 2;
     // yolact.rs:216-217 + :163: the two tiles as one batch
@@ -1975,6 +2059,123 @@ int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, fl
     return YH_OK;
 }
 
+// ---- audit hooks (profiles/r03_fault_audit.md): where every buffer of a handle lives, and what a captured step consists of ----
+// One line per allocation: kind, name (layer tensors by their DESIGN.md names), [base, end), size and the offsets of base and
+// end inside their 2 MiB page - the three GPU memory-access faults of round 2 all hit an address 8 KiB below a 2 MiB boundary.
+int yh_debug_alloc_map(yh_engine* h, char* out, size_t cap) {
+    if (!h || !out || cap < 2) return YH_EINVAL;
+    std::string t;
+    char ln[320];
+    auto line = [&](const char* kind, const std::string& name, const void* base, size_t bytes) {
+        const unsigned long long b = (unsigned long long)(uintptr_t)base, e = b + bytes;
+        snprintf(ln, sizeof ln, "%-7s %-14s base 0x%012llx end 0x%012llx bytes %12zu  base%%2MiB 0x%06llx  end%%2MiB 0x%06llx\n", kind, name.c_str(), b, e, bytes,
+                 b & 0x1FFFFFull, e & 0x1FFFFFull);
+        t += ln;
+    };
+    std::map<const void*, std::string> names;
+    for (const auto& kv : h->named) if (!names.count(kv.second.d)) names[kv.second.d] = kv.first;
+    for (const auto& kv : h->named) if (kv.second.q && !names.count(kv.second.q)) names[kv.second.q] = kv.first + ".e4m3";
+    names[h->in_buf[0]] = "in_u8[0]"; names[h->in_buf[1]] = "in_u8[1]"; names[h->splitk_ws] = "splitk_ws"; names[h->splitk_ws_side] = "splitk_ws_side";
+    names[h->blob_dev] = "weight_blob"; names[h->side_word] = "side_word"; names[h->priors_dev] = "priors";
+    names[h->det.cls_count] = "det.cls_count"; names[h->det.cand] = "det.cand"; names[h->det.surv_score] = "det.surv_score"; names[h->det.surv_prior] = "det.surv_prior";
+    names[h->det.surv_box] = "det.surv_box"; names[h->det.det_count] = "det.det_count"; names[h->det.dets] = "det.dets"; names[h->det.det_crop] = "det.det_crop"; names[h->det.masks] = "det.masks";
+    for (size_t i = 0; i < h->panels.size(); ++i) {
+        const Panel& p = h->panels[i];
+        const std::string nm = "panel" + std::to_string(i);
+        names[p.w] = nm + ".w"; names[p.bias] = nm + ".bias";
+        if (p.w8) names[p.w8] = nm + ".w8";
+        if (p.scale) names[p.scale] = nm + ".scale";
+        if (p.rs_table) names[p.rs_table] = nm + ".rs";
+    }
+    for (size_t i = 0; i < h->allocs.size(); ++i) {
+        auto it = names.find(h->allocs[i]);
+        line("device", it != names.end() ? it->second : "alloc" + std::to_string(i), h->allocs[i], h->alloc_bytes[i]);
+    }
+    if (h->out_f32) line("device", "out_f32", h->out_f32, h->out_f32_cap * 4);
+    if (h->frame_dev) line("device", "frame_dev", h->frame_dev, h->frame_cap);
+    if (h->rs_tmp) line("device", "rs_tmp", h->rs_tmp, h->rs_tmp_cap);
+    for (int k = 0; k < 2; ++k) if (h->stage[k]) line("pinned", "stage" + std::to_string(k), h->stage[k], yh_engine::kStageBytes);
+    snprintf(out, cap, "%s", t.c_str());
+    return (int)t.size() < (int)cap ? YH_OK : YH_EOVERFLOW;
+}
+
+// The step for the current batch size, captured (not instantiated) under the handle's current tuning: one line per graph
+// node - kernel symbol, grid, block, and for the single-struct kernels of this library the pointers and sizes in the launch
+// argument - plus node / edge / root counts. Two captures (with and without the forks) can then be diffed as text.
+int yh_debug_graph_nodes(yh_engine* h, int32_t with_tail, char* out, size_t cap) {
+    if (!h || !out || cap < 2) return YH_EINVAL;
+    if (!h->weights_loaded || h->cur_n < 1) return h->fail(YH_ESTATE, "weights and input must be set");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = wait_input(h);
+    if (rc) return rc;
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    h->capturing = true;
+    rc = enqueue_all(h, h->cur_n, with_tail);
+    h->capturing = false;
+    const hipError_t ce = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess || !g) return h->fail(YH_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    size_t nn = 0, ne = 0, nr = 0;
+    hipGraphGetNodes(g, nullptr, &nn);
+    hipGraphGetEdges(g, nullptr, nullptr, &ne);
+    hipGraphGetRootNodes(g, nullptr, &nr);
+    std::vector<hipGraphNode_t> nodes(nn);
+    if (nn) hipGraphGetNodes(g, nodes.data(), &nn);
+    std::string t;
+    char ln[640];
+    snprintf(ln, sizeof ln, "# nodes %zu edges %zu roots %zu (batch %d, with_tail %d)\n", nn, ne, nr, h->cur_n, with_tail);
+    t += ln;
+    std::vector<std::string> lines;
+    for (hipGraphNode_t nd : nodes) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nd, &ty) != hipSuccess) continue;
+        if (ty == hipGraphNodeTypeKernel) {
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) { lines.push_back("kernel ?"); continue; }
+            const char* nm = hipKernelNameRefByPtr(kp.func, h->stream);
+            std::string name = nm ? nm : "?";
+            std::string args;
+            if (kp.kernelParams && kp.kernelParams[0]) {
+                if (name.find("conv_igemm_f16") != std::string::npos || name.find("splitk_reduce_f16") != std::string::npos) {
+                    const ConvParams* q = (const ConvParams*)kp.kernelParams[0];
+                    snprintf(ln, sizeof ln, " x %p w %p bias %p res %p y %p y8 %p x2 %p w2 %p y2 %p scale %p partial %s M %d C %d ksteps %d k_slices %d m_tile0 %d ch_tile0 %d n_ch_tiles %d x_bytes %u w_bytes %u",
+                             (const void*)q->x, (const void*)q->w, (const void*)q->bias, (const void*)q->res, (void*)q->y, (void*)q->y8, (const void*)q->x2, (const void*)q->w2, (void*)q->y2,
+                             (const void*)q->scale, !q->partial ? "-" : (q->partial == h->splitk_ws ? "ws_main" : (q->partial == h->splitk_ws_side ? "ws_side" : "?")), q->M, q->C, q->ksteps, q->k_slices,
+                             q->m_tile0, q->ch_tile0, q->n_ch_tiles, q->x_bytes, q->w_bytes);
+                    args = ln;
+                } else if (name.find("det_") != std::string::npos) {
+                    const DetectParams* q = (const DetectParams*)kp.kernelParams[0];
+                    snprintf(ln, sizeof ln, " heads %p proto %p cand %p dets %p masks %p n %d", (const void*)q->heads, (const void*)q->proto, (void*)q->cand, (void*)q->dets, (void*)q->masks, q->n);
+                    args = ln;
+                } else if (name.find("stem_pool_f16") != std::string::npos) {
+                    const StemPoolParams* q = (const StemPoolParams*)kp.kernelParams[0];
+                    snprintf(ln, sizeof ln, " x %p rgb %s w %p pool %p n %d", (const void*)q->x, q->rgb == h->in_buf[0] ? "in_u8[0]" : (q->rgb == h->in_buf[1] ? "in_u8[1]" : (q->rgb ? "?" : "-")), (const void*)q->w, (void*)q->pool, q->n);
+                    args = ln;
+                }
+            }
+            snprintf(ln, sizeof ln, "kernel grid %u,%u,%u block %u shmem %u %s", kp.gridDim.x, kp.gridDim.y, kp.gridDim.z, kp.blockDim.x, kp.sharedMemBytes, name.c_str());
+            lines.push_back(std::string(ln) + args);
+        } else if (ty == hipGraphNodeTypeMemset) {
+            hipMemsetParams mp;
+            memset(&mp, 0, sizeof mp);
+            hipGraphMemsetNodeGetParams(nd, &mp);
+            snprintf(ln, sizeof ln, "memset dst %s width %zu height %zu elem %u value %u", mp.dst == (void*)h->side_word ? "side_word" : (mp.dst == (void*)h->det.cls_count ? "det.cls_count" : "?"),
+                     mp.width, mp.height, mp.elementSize, mp.value);
+            lines.push_back(ln);
+        } else {
+            snprintf(ln, sizeof ln, "node type %d", (int)ty);
+            lines.push_back(ln);
+        }
+    }
+    hipGraphDestroy(g);
+    std::sort(lines.begin(), lines.end());   // (node order of a multi-branch graph is not a property of the step)
+    for (const std::string& l : lines) t += l + "\n";
+    snprintf(out, cap, "%s", t.c_str());
+    return t.size() < cap ? YH_OK : YH_EOVERFLOW;
+}
+
 // ---- measurement hooks -------------------------------------------------------------------------
 // One profile entry per KERNEL launch (so that the averages agree with rocprofv3's per-kernel stats):
 // a conv op planned as two launches (wave-quantisation tail, channel split, split-K + reduce) gives
@@ -2015,7 +2216,9 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
     HIPCHK(h, hipSetDevice(h->dev));
     const int n = h->cur_n;
     std::vector<ProfEntry> ent;
-    int rc = build_profile_entries(h, n, with_tail, &ent);
+    int rc = wait_input(h);
+    if (rc) return rc;
+    rc = build_profile_entries(h, n, with_tail, &ent);
     if (rc) return rc;
     const int nl = (int)ent.size();
     std::vector<hipEvent_t> ev((size_t)nl * 2);

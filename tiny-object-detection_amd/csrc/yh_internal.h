@@ -12,6 +12,22 @@ namespace yh {
 typedef _Float16 half_t;
 
 // ---------------------------------------------------------------------------------------------
+// Tracing: roctx ranges around set-input / forward / tail / read-back and the TFLite op groups, so that a
+// `rocprofv3 --marker-trace --kernel-trace -- python3 bench.py` timeline reads without symbol archaeology. The two entry
+// points are looked up in the PROCESS at first use (dlsym(RTLD_DEFAULT)): rocprofv3 --marker-trace preloads
+// librocprofiler-sdk-roctx.so and a host may link it; when neither did, a range costs one null test. No dependency.
+// ---------------------------------------------------------------------------------------------
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi& roctx_api();   // engine.hip
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char* name) { const RoctxApi& r = roctx_api(); on = r.push && r.pop; if (on) r.push(name); }
+    ~TraceRange() { if (on) roctx_api().pop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+
+// ---------------------------------------------------------------------------------------------
 // Convolution as implicit GEMM (conv_igemm.hip).
 //   D[ch][m] = sum_k Wt[ch][k] * X[m][k],  m = (n, p, q) row-major,  k = ((r*S + s)*C + c).
 // Activations are NHWC f16 with C a multiple of 8 (C >= 64: multiple of 64; C == 8: "small-C"

@@ -74,4 +74,54 @@ std::vector<std::vector<float>> Yolact::classify_tile_outputs(const std::uint8_t
     return results;
 }
 
+// ---- YolactGroup ---------------------------------------------------------------------------------------------------
+YolactGroup YolactGroup::init(const GroupOptions& opt) {
+    YolactGroup y;
+    y.opt_ = opt;
+    yh_config cfg;
+    yh_default_config(&cfg);
+    cfg.input_size = opt.input_size;
+    cfg.backbone = opt.backbone;
+    cfg.max_batch = opt.frames_per_member;
+    cfg.precision = opt.precision;
+    y.max_dets_ = cfg.max_dets;
+    std::vector<std::int32_t> devs(opt.devices.begin(), opt.devices.end());
+    if (yh_group_create(&cfg, devs.data(), static_cast<std::int32_t>(devs.size()), &y.g_) != YH_OK)
+        expect_failed("must create interpreter builder", yh_group_last_error(nullptr));                     // yolact.rs:25, once per device
+    yh_engine* m0 = yh_group_member(y.g_, 0);
+    const std::size_t n = yh_weights_nbytes(m0);
+    std::vector<unsigned char> blob(n);
+    if (yh_weights_generate(m0, opt.seed, blob.data(), n) != YH_OK) expect_failed("failed to load model", yh_last_error(m0));   // :20
+    if (yh_group_load_weights_host(y.g_, blob.data(), n) != YH_OK) expect_failed("failed to allocate tensors.", yh_group_last_error(y.g_));   // :35
+    std::int32_t pd[2] = {0, 0};
+    yh_proto_dims(m0, pd);
+    y.hp_ = pd[0]; y.wp_ = pd[1];
+    return y;
+}
+
+YolactGroup::YolactGroup(YolactGroup&& o) noexcept : g_(o.g_), opt_(std::move(o.opt_)), hp_(o.hp_), wp_(o.wp_), max_dets_(o.max_dets_) { o.g_ = nullptr; }
+YolactGroup::~YolactGroup() { if (g_) yh_group_destroy(g_); }
+int YolactGroup::members() const { return yh_group_size(g_); }
+std::string YolactGroup::weights_replication() const { return yh_group_weights_replication(g_); }
+
+void YolactGroup::evaluate(const std::uint8_t* frames, int n) {
+    if (yh_group_evaluate(g_, frames, n, 1) != YH_OK) expect_failed("invoke failed", yh_group_last_error(g_));   // yolact.rs:163
+}
+
+FrameDetections YolactGroup::detections(int frame, bool want_masks) {
+    FrameDetections out;
+    out.dets.resize(static_cast<std::size_t>(max_dets_));
+    if (want_masks) out.masks.resize(static_cast<std::size_t>(max_dets_) * hp_ * wp_);
+    std::int32_t nd = 0;
+    if (yh_group_read_detections(g_, frame, &nd, out.dets.data(), max_dets_, want_masks ? out.masks.data() : nullptr, out.masks.size()) != YH_OK)
+        expect_failed("must data", yh_group_last_error(g_));                                                 // yolact.rs:173,:180
+    out.dets.resize(static_cast<std::size_t>(nd));
+    if (want_masks) out.masks.resize(static_cast<std::size_t>(nd) * hp_ * wp_);
+    return out;
+}
+
+void YolactGroup::sync() {
+    if (yh_group_sync(g_) != YH_OK) expect_failed("invoke failed", yh_group_last_error(g_));
+}
+
 }  // namespace tod

@@ -56,4 +56,44 @@ private:
     InitOptions opt_;
 };
 
+// One process, N devices: the frame loop of src/main.rs:63-75 / src/scene.rs:77-92 with N frames in flight. A camera batch
+// of host frames goes in, the detections of every frame come out; frames shard over the members in contiguous blocks
+// (yh_group_*: one host worker thread + stream per device, weights replicated once, no per-step collective).
+struct GroupOptions {
+    std::vector<int> devices = {0};    // one member per entry; an entry may repeat (two members then share that device)
+    int input_size = 550, backbone = YH_BACKBONE_R50;
+    int frames_per_member = 8;         // yh_config.max_batch of every member
+    int precision = YH_PRECISION_F16;
+    std::uint64_t seed = 1;            // seeded synthetic weights (the reference's model file is absent)
+};
+
+struct FrameDetections {
+    std::vector<yh_detection> dets;
+    std::vector<std::uint8_t> masks;   // dets.size() x Hp x Wp, 0/1 (empty unless asked for)
+};
+
+class YolactGroup {
+public:
+    static YolactGroup init(const GroupOptions& opt = GroupOptions());
+    YolactGroup(YolactGroup&& o) noexcept;
+    YolactGroup& operator=(YolactGroup&&) = delete;
+    YolactGroup(const YolactGroup&) = delete;
+    ~YolactGroup();
+
+    int members() const;
+    int capacity() const { return members() * opt_.frames_per_member; }   // frames per evaluate
+    std::string weights_replication() const;
+    // n frames of u8 RGB [n][S][S][3]: enqueues them on the members and returns (the GPUs run on; the frames are free again)
+    void evaluate(const std::uint8_t* frames, int n);
+    // waits for the member that holds `frame` of the last evaluate and returns its detections
+    FrameDetections detections(int frame, bool want_masks = false);
+    void sync();
+
+private:
+    YolactGroup() = default;
+    yh_group* g_ = nullptr;
+    GroupOptions opt_;
+    int hp_ = 0, wp_ = 0, max_dets_ = 100;
+};
+
 }  // namespace tod

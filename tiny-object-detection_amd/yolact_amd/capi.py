@@ -84,6 +84,20 @@ SYMBOLS = [
     ("yh_group_broadcast_weights", _i, [C.POINTER(_vp), _i, _i]),
     ("yh_rccl_unique_id", _i, [_vp]),
     ("yh_rank_broadcast_weights", _i, [_vp, _vp, _i, _i, _i]),
+    ("yh_group_create", _i, [C.POINTER(Config), C.POINTER(_i), _i, C.POINTER(_vp)]),
+    ("yh_group_destroy", None, [_vp]),
+    ("yh_group_last_error", C.c_char_p, [_vp]),
+    ("yh_group_size", _i, [_vp]),
+    ("yh_group_member", _vp, [_vp, _i]),
+    ("yh_group_load_weights_host", _i, [_vp, _vp, _sz]),
+    ("yh_group_replicate_weights", _i, [_vp]),
+    ("yh_group_weights_replication", C.c_char_p, [_vp]),
+    ("yh_group_fp8_calibrate", _i, [_vp]),
+    ("yh_group_evaluate", _i, [_vp, _vp, _i, _i]),
+    ("yh_group_evaluate_device", _i, [_vp, C.POINTER(_vp), C.POINTER(_i), _i]),
+    ("yh_group_sync", _i, [_vp]),
+    ("yh_group_read_detections", _i, [_vp, _i, C.POINTER(_i), _vp, _i, _vp, _sz]),
+    ("yh_group_frame_owner", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("yh_input_dims", _i, [_vp, C.POINTER(_i * 4)]),
     ("yh_set_input_u8", _i, [_vp, _vp, _i]),
     ("yh_set_input_u8_device", _i, [_vp, _vp, _i]),
@@ -130,6 +144,8 @@ SYMBOLS = [
     ("yh_debug_read_tensor", _i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_read_tensor_frame", _i, [_vp, C.c_char_p, _i, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
+    ("yh_debug_alloc_map", _i, [_vp, C.c_char_p, _sz]),
+    ("yh_debug_graph_nodes", _i, [_vp, _i, C.c_char_p, _sz]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_quantize_e4m3", _i, [_vp, _vp, _sz, C.c_float, _vp]),
@@ -409,6 +425,18 @@ class Engine:
         self._chk(self.L.yh_time_steps(self.h, 1 if with_tail else 0, steps, C.byref(ms)))
         return ms.value
 
+    def alloc_map(self):
+        """Audit hook: one text line per buffer of the handle (base, end, size, offsets inside their 2 MiB pages)."""
+        buf = C.create_string_buffer(1 << 20)
+        self._chk(self.L.yh_debug_alloc_map(self.h, buf, len(buf)))
+        return buf.value.decode()
+
+    def graph_nodes(self, with_tail=True):
+        """Audit hook: the captured step for the current batch size, one sorted text line per graph node."""
+        buf = C.create_string_buffer(1 << 20)
+        self._chk(self.L.yh_debug_graph_nodes(self.h, 1 if with_tail else 0, buf, len(buf)))
+        return buf.value.decode()
+
     def last_conv_launches(self):
         return self.L.yh_debug_last_conv_launches(self.h)
 
@@ -517,6 +545,99 @@ class Engine:
         lb, cb, mb, pb = _f16_bits(loc), _f16_bits(conf), _f16_bits(mask), _f16_bits(proto)
         self._chk(self.L.yh_op_detect(self.h, _p(lb), _p(cb), _p(mb), _p(pb), n))
         self.n = n
+
+
+class Group:
+    """RAII wrapper of yh_group: one process, one engine per device (devices may repeat), frames sharded in contiguous blocks."""
+
+    def __init__(self, devices, **engine_kw):
+        self.L = load_library()
+        cfg = Config()
+        self.L.yh_default_config(C.byref(cfg))
+        kw = dict(input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100, conf_thresh=0.05, nms_thresh=0.5,
+                  use_graph=True, debug_tensors=False, precision=PRECISION_F16, tune=None)
+        kw.update(engine_kw)
+        cfg.backbone, cfg.input_size, cfg.max_batch = kw["backbone"], kw["input_size"], kw["max_batch"]
+        cfg.num_classes, cfg.top_k, cfg.max_dets = kw["num_classes"], kw["top_k"], kw["max_dets"]
+        cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = kw["conf_thresh"], kw["nms_thresh"], 1 if kw["use_graph"] else 0
+        cfg.debug_tensors, cfg.precision = (1 if kw["debug_tensors"] else 0), kw["precision"]
+        if kw["tune"]:
+            cfg.tune = Tuning.of(**kw["tune"])
+        devs = (C.c_int32 * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self.L.yh_group_create(C.byref(cfg), devs, len(devices), C.byref(g))
+        if rc != OK:
+            raise YhError(rc, self.L.yh_group_last_error(None).decode())
+        self.g, self.cfg, self.n, self.S, self.max_batch = g, cfg, len(devices), kw["input_size"], kw["max_batch"]
+        self.members = []
+        for i in range(self.n):                 # non-owning Engine views of the members (the group owns the handles)
+            e = Engine.__new__(Engine)
+            e.L, e.cfg, e.h, e._tune = self.L, cfg, C.c_void_p(self.L.yh_group_member(self.g, i)), {}
+            e.S, e.C, e.max_batch, e.n = kw["input_size"], kw["num_classes"], kw["max_batch"], 0
+            e.P = self.L.yh_num_priors(e.h)
+            d = (C.c_int32 * 2)()
+            self.L.yh_proto_dims(e.h, C.byref(d))
+            e.hp, e.wp = d[0], d[1]
+            e.close = lambda: None              # never yh_destroy a member
+            self.members.append(e)
+        self.hp, self.wp = self.members[0].hp, self.members[0].wp
+
+    def close(self):
+        if getattr(self, "g", None):
+            for e in self.members:
+                e.h = None
+            self.L.yh_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise YhError(rc, self.L.yh_group_last_error(self.g).decode())
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._chk(self.L.yh_group_load_weights_host(self.g, _p(blob), blob.size))
+
+    def replicate_weights(self):
+        self._chk(self.L.yh_group_replicate_weights(self.g))
+
+    def weights_replication(self):
+        return self.L.yh_group_weights_replication(self.g).decode()
+
+    def fp8_calibrate(self):
+        self._chk(self.L.yh_group_fp8_calibrate(self.g))
+
+    def evaluate(self, frames, with_tail=True):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n = frames.shape[0]
+        assert frames.shape == (n, self.S, self.S, 3), frames.shape
+        self._chk(self.L.yh_group_evaluate(self.g, _p(frames), n, 1 if with_tail else 0))
+        self.total = n
+
+    def evaluate_device(self, dev_ptrs, counts, with_tail=True):
+        ptrs = (C.c_void_p * self.n)(*[C.c_void_p(p) for p in dev_ptrs])
+        cnt = (C.c_int32 * self.n)(*counts)
+        self._chk(self.L.yh_group_evaluate_device(self.g, ptrs, cnt, 1 if with_tail else 0))
+        self.total = int(sum(counts))
+
+    def sync(self):
+        self._chk(self.L.yh_group_sync(self.g))
+
+    def frame_owner(self, frame):
+        m, l = C.c_int32(), C.c_int32()
+        self._chk(self.L.yh_group_frame_owner(self.g, frame, C.byref(m), C.byref(l)))
+        return m.value, l.value
+
+    def detections(self, frame, want_masks=True):
+        nd = C.c_int32()
+        dets = (Detection * self.cfg.max_dets)()
+        masks = np.zeros((self.cfg.max_dets, self.hp, self.wp), np.uint8) if want_masks else None
+        self._chk(self.L.yh_group_read_detections(self.g, frame, C.byref(nd), C.cast(dets, C.c_void_p), self.cfg.max_dets,
+                                                  _p(masks) if want_masks else None, masks.size if want_masks else 0))
+        out = [dict(class_id=d.class_id, prior=d.prior, score=d.score, box=tuple(d.box)) for d in dets[:nd.value]]
+        return out, (masks[:nd.value] if want_masks else None)
 
 
 class Scene:
