@@ -104,7 +104,8 @@ typedef struct yh_tuning {
     int32_t k1_min1;         /* streaming tiles: launches of at least this many tiles per CU, in QUARTERS (8 = 2 per CU), for the 1x1
                               * layers and the 64- / 128-channel 3x3 layers */
     int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
-    int32_t reserved[1];     /* -1 */
+    int32_t chain;           /* identity bottleneck blocks of layers 1-2 as ONE launch each: 3x3 conv + 1x1 expand conv with the residual
+                              * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches; 1) */
 } yh_tuning;
 
 typedef struct yh_config {

@@ -30,6 +30,38 @@ def _single(ya, blob, S, max_batch, blocks, **kw):
     return out
 
 
+class _Hip:
+    """Device / pinned buffers straight from the HIP runtime the library itself is linked to (no torch: its bundled HIP runtime
+    cannot initialise the device once the system one has - 'no ROCm-capable device' - in a process that loaded our library first)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C, self.L = C, C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        self.bufs, self.pinned = [], []
+
+    def device(self, arr):
+        C = self.C
+        p = C.c_void_p()
+        assert self.L.hipMalloc(C.byref(p), C.c_size_t(arr.nbytes)) == 0
+        assert self.L.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), 1) == 0   # hipMemcpyHostToDevice
+        self.bufs.append(p)
+        return p.value
+
+    def pinned_like(self, shape):
+        C = self.C
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        assert self.L.hipHostMalloc(C.byref(p), C.c_size_t(n), 0) == 0
+        self.pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).reshape(shape)
+
+    def close(self):
+        for p in self.bufs:
+            self.L.hipFree(p)
+        for p in self.pinned:
+            self.L.hipHostFree(p)
+
+
 def _same(a, b):
     (da, ma), (db, mb) = a, b
     return da == db and np.array_equal(ma, mb)
@@ -73,22 +105,21 @@ def test_group_of_two_members_on_one_device_equals_single_engine(built, S, per):
 
 
 def test_group_evaluate_device_with_resident_frames(built):
-    torch = pytest.importorskip("torch")
     import yolact_amd as ya
     S, per = 256, 3
     g = ya.Group([0, 0, 0], input_size=S, max_batch=per, conf_thresh=TH)
     blob = g.members[0].generate_weights(seed=1)
     g.load_weights(blob)
-    gen = torch.Generator(device="cuda:0").manual_seed(7)
-    bufs = [torch.randint(0, 256, (per, S, S, 3), dtype=torch.uint8, device="cuda:0", generator=gen) for _ in range(3)]
-    torch.cuda.synchronize()
-    g.evaluate_device([b.data_ptr() for b in bufs], [3, 0, 2])           # member 1 sits out
+    hip = _Hip()
+    host = [np.random.default_rng(70 + i).integers(0, 256, (per, S, S, 3), dtype=np.uint8) for i in range(3)]
+    ptrs = [hip.device(a) for a in host]
+    g.evaluate_device(ptrs, [3, 0, 2])                                   # member 1 sits out
     got = [g.detections(f) for f in range(5)]
-    want = _single(ya, blob, S, per, [bufs[0].cpu().numpy(), bufs[2].cpu().numpy()[:2]])
+    want = _single(ya, blob, S, per, [host[0], host[2][:2]])
     assert g.frame_owner(3) == (2, 0)
     for f in range(5):
         assert _same(got[f], want[f]), f
-    g.close()
+    g.close(); hip.close()
 
 
 def test_cpp_group_host_matches_python(built, tmp_path):
@@ -140,12 +171,8 @@ def test_set_input_overlaps_the_running_step_and_changes_no_bit(built, n):
                 assert np.array_equal(a, b), k
             for a, b in zip(got[k][1], want[k][1]):
                 assert _same(a, b), k
-    sources = [np.empty((n, S, S, 3), np.uint8)]
-    try:
-        import torch
-        sources.append(torch.empty((n, S, S, 3), dtype=torch.uint8).pin_memory().numpy())
-    except Exception:   # noqa: BLE001 - no torch: the pageable source alone
-        pass
+    hip = _Hip()
+    sources = [np.empty((n, S, S, 3), np.uint8), hip.pinned_like((n, S, S, 3))]     # pageable, pinned (hipHostMalloc)
     for buf in sources:
         got = []
         buf[:] = F[0]; eng.set_input(buf); buf[:] = 0xAB
@@ -159,7 +186,7 @@ def test_set_input_overlaps_the_running_step_and_changes_no_bit(built, n):
     # steps that re-use the frames last set (no yh_set_input_* in between) read the same buffer again
     eng.evaluate()
     assert all(np.array_equal(a, b) for a, b in zip(read()[0], want[K - 1][0]))
-    eng.close()
+    eng.close(); hip.close()
 
 
 def test_bench_single_process_mode_prints_the_contract_line(built):

@@ -1,0 +1,351 @@
+// bneck.hip — a whole ResNet bottleneck tail as ONE kernel ("cut inter-kernel HBM traffic in layers 1-2").
+//
+// Inside interpreter.invoke() (/root/reference/src/yolact.rs:163) a bottleneck block is CONV_2D -> CONV_2D -> CONV_2D + ADD
+// (+ the next block's first CONV_2D). As separate launches every block writes and re-reads its 64 / 128-channel intermediates
+// and its 4x-wide output: 16 tensor-units of HBM traffic per identity block (unit = pixels x planes x 2 B; at batch 64 layer 1
+// moves 2.5 GB per block at 0.49 of the HBM peak, 32 % of the step). This kernel runs, for one tile of TM output pixels,
+//
+//   b  = relu(conv3x3(a; stride, pad 1) + bias_b)                       planes -> planes      (kept in LDS)
+//   y  = relu(W_c b + bias_c + x)                                        planes -> 4 planes    (written: the next block's residual)
+//   a' = relu(W_a' y + bias_a')                                          4 planes -> planes    (written: the next block's conv_b input)
+//
+// so a block reads a (1 unit, halo through L2) and x (4) and writes y (4) and a' (1): 10 units instead of 16, and three
+// launches become one. The 1x1 convolutions need no halo, so nothing is recomputed; the 3x3 loads its taps through the
+// normal implicit-GEMM loader.
+//
+// Bit-transparent by construction: every output element accumulates the same v_mfma_f32_32x32x16_f16 products in the same
+// order as conv_igemm_f16's streaming tiles (k = 64-channel chunk outer, taps inner, four 16-deep slices per step), the
+// epilogues apply the same f32 operations in the same order (acc + bias, + residual, max 0, round to f16), and the
+// intermediates are rounded to f16 exactly where the separate launches store them. tests/test_gpu_bneck.py compares the
+// fused engine with the unfused one bit for bit.
+//
+// LDS (one array; PL = 64, TM = 256: 80 KB -> two workgroups per CU):
+//   [0, A)        phase 1: weight tile [PL][128 B] + activation tile [TM][128 B] of the current k-step (single stage, as the
+//                 streaming tiles); afterwards Wt2 (the expand conv's weight k-tiles of the current 64-channel chunk)
+//                 and Bt = b as PL/64 activation k-tiles [TM][128 B]
+//   [A, A + S)    stage [TM][128 B]: one 64-channel chunk of a row - first the residual (row loads), then in place the rounded y
+//                 chunk, which is both stored from here with whole-row 16-byte stores and read back as the B operand of a'
+//   [.., + W3)    Wt3: W_a' k-tile [PL][128 B] of the current chunk
+// Every tile row is 128 bytes with logical 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7): the LDS-DMA image
+// is lane-linear, so the permutation is on each lane's SOURCE address (conv_igemm.hip), and ds_read_b128 fragment reads are
+// conflict free.
+#include "yh_internal.h"
+
+namespace yh {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <int A, int B>
+struct bmax { static constexpr int v = A > B ? A : B; };
+
+// vmcnt(N) (all but the N youngest vector-memory operations of this wave have completed), lgkmcnt(0), workgroup barrier.
+template <int N>
+__device__ __forceinline__ void bar_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+}  // namespace
+
+// WCH x WM: wave grid of the PL-channel GEMMs (conv_b, a'); W2C x W2M: of the 64-channel chunk GEMM (the expand conv).
+template <int PL, int TM, int WCH, int WM, int W2C, int W2M, bool NEXT>
+__global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
+    static_assert(PL % 64 == 0 && TM % 32 == 0 && WCH * WM == 4 && W2C * W2M == 4, "four waves");
+    constexpr int KT = PL / 64;                     // 64-channel k-tiles of a PL-channel tensor
+    constexpr int WTC = PL / WCH, WTM = TM / WM, TC = WTC / 32, TMT = WTM / 32;          // PL-channel GEMMs
+    constexpr int W2TC = 64 / W2C, W2TM = TM / W2M, TC2 = W2TC / 32, TMT2 = W2TM / 32;   // chunk GEMM
+    static_assert(WTC % 32 == 0 && WTM % 32 == 0 && W2TC % 32 == 0 && W2TM % 32 == 0, "wave tiles are multiples of the 32 x 32 MFMA tile");
+    constexpr int XL = TM / 32, WL = PL / 32;       // LDS-DMA passes (32 rows each) of an activation / PL-row weight tile
+    constexpr int NOC = (4 * PL) / 64;              // 64-channel chunks of the block output
+    constexpr int P1_BYTES = (PL + TM) * 128;       // phase 1: one k-step's weight + activation tile
+    constexpr int WT2_BYTES = KT * 64 * 128, BT_BYTES = KT * TM * 128;
+    constexpr int A_BYTES = bmax<P1_BYTES, WT2_BYTES + BT_BYTES>::v;
+    constexpr int ST_BYTES = TM * 128, WT3_BYTES = NEXT ? PL * 128 : 0;
+    constexpr int LDS_BYTES = A_BYTES + ST_BYTES + WT3_BYTES;
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    lds_char* const lds3 = (lds_char*)lds;
+    char* const wt2 = lds;                          // after phase 1
+    char* const bt = lds + WT2_BYTES;
+    char* const stage = lds + A_BYTES;
+    char* const wt3 = lds + A_BYTES + ST_BYTES;
+
+    // XCD-aware bijective remap of the tile id (conv_igemm.hip)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = tile * TM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pc = tid & 7, rb = tid >> 3;          // DMA / row-pass role: physical chunk pc of rows rb + 32 d
+    const int lc = pc ^ ((rb >> 1) & 7);            // ... holds logical chunk lc
+    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
+    const int PQ = p.P * p.Q;
+    const int C4 = 4 * PL;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? p.w1n : p.w3), 0, (int)(NEXT ? p.w1n_bytes : 0u), 0x00020000);
+
+    // ---- residual rows of chunk oc -> registers (16 bytes per lane and pass: rows rb + 32 d, logical chunk lc)
+    half8 resv[XL];
+    auto load_res = [&](int oc) {
+#pragma unroll
+        for (int d = 0; d < XL; ++d) {
+            const int m = m0 + rb + 32 * d;
+            resv[d] = *(const half8*)(p.res + (long long)(m < p.M ? m : 0) * C4 + oc * 64 + lc * 8);
+        }
+    };
+    load_res(0);   // (lands under phase 1)
+
+    // ---- phase 1: b = relu(conv3x3(a) + bias_b), streaming-tile loop (one LDS stage; the co-resident workgroup overlaps)
+    int xbase[XL], xih[XL], xiw[XL];
+#pragma unroll
+    for (int d = 0; d < XL; ++d) {
+        const int m = m0 + rb + 32 * d;
+        if (m < p.M) {
+            const int n = m / PQ, rem = m - n * PQ, op = rem / p.Q, oq = rem - op * p.Q;
+            xih[d] = op * p.stride - 1;
+            xiw[d] = oq * p.stride - 1;
+            xbase[d] = (int)(n * p.a_img_stride) + (xih[d] * p.W + xiw[d]) * PL + lc * 8;
+        } else { xih[d] = -(1 << 24); xiw[d] = 0; xbase[d] = 0; }
+    }
+    const int a1_row = ((wave / WM) * WTC + l31) * 128, b1_row = ((wave % WM) * WTM + l31) * 128;
+    f32x16 acc[TC][TMT];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TMT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    {
+        const unsigned wbase = (unsigned)((rb * (9 * PL) + lc * 8) * 2);
+        for (int kc = 0; kc < PL; kc += 64)
+            for (int r = 0; r < 3; ++r)
+                for (int s = 0; s < 3; ++s) {
+                    if (kc | r | s) __syncthreads();           // every wave is done reading the previous step's tiles
+                    lds_char* const dstw = lds3 + wave * 1024;
+                    const int wk = (r * 3 + s) * PL + kc;      // K index of this step in the [(r, s, c)] panel
+#pragma unroll
+                    for (int d = 0; d < WL; ++d)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, dstw + d * 4096, 16, (int)(wbase + (unsigned)((32 * d) * (9 * PL) + wk) * 2u), 0, 0, 0);
+                    const int toff = (r * p.W + s) * PL + kc;
+#pragma unroll
+                    for (int d = 0; d < XL; ++d) {
+                        const bool ok = (unsigned)(xih[d] + r) < (unsigned)p.H && (unsigned)(xiw[d] + s) < (unsigned)p.W;
+                        const unsigned voff = ok ? (unsigned)(xbase[d] + toff) * 2u : p.a_zero_off;   // padded taps read the allocation's zero block
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dstw + PL * 128 + d * 4096, 16, (int)voff, 0, 0, 0);
+                    }
+                    __syncthreads();                           // vmcnt(0) + barrier: the tiles have landed and are visible
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int co = ((2 * kk + lh) ^ swz) << 4;
+                        half8 fa[TC], fb[TMT];
+#pragma unroll
+                        for (int i = 0; i < TC; ++i) fa[i] = *(const half8*)(lds + a1_row + i * 4096 + co);
+#pragma unroll
+                        for (int j = 0; j < TMT; ++j) fb[j] = *(const half8*)(lds + PL * 128 + b1_row + j * 4096 + co);
+#pragma unroll
+                        for (int i = 0; i < TC; ++i)
+#pragma unroll
+                            for (int j = 0; j < TMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+    }
+    __syncthreads();   // region A is reused
+    // the expand conv's weight k-tiles of chunk 0 (rows 0 .. 63 of W_c) travel while b is rounded into LDS
+    auto dma_wt2 = [&](int oc) {
+        lds_char* const dstw = lds3 + wave * 1024;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, dstw + kt * 8192 + d * 4096, 16, (int)((unsigned)(((oc * 64 + rb + 32 * d) * PL + kt * 64 + lc * 8) * 2)), 0, 0, 0);
+    };
+    auto dma_wt3 = [&](int oc) {
+        if (!NEXT) return;
+        lds_char* const dstw = lds3 + (A_BYTES + ST_BYTES) + wave * 1024;
+#pragma unroll
+        for (int d = 0; d < WL; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, dstw + d * 4096, 16, (int)((unsigned)(((rb + 32 * d) * C4 + oc * 64 + lc * 8) * 2)), 0, 0, 0);
+    };
+    constexpr int N3 = NEXT ? WL : 0;   // LDS-DMA instructions per wave of dma_wt3 (dma_wt2: 2 KT)
+    dma_wt2(0);
+    {   // b -> Bt: bias, ReLU, round; lane holds pixel (wm, j, l31) and channels (wc, i, 8 g + 4 lh + e)
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (wave / WM) * WTC + i * 32 + 8 * g + 4 * lh;
+                const f32x4 b4 = *(const f32x4*)(p.bias2 + ch);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) {
+                    const int m = (wave % WM) * WTM + j * 32 + l31;
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf(acc[i][j][4 * g + e] + b4[e], 0.0f);
+                    *(half4*)(bt + (ch >> 6) * (TM * 128) + m * 128 + ((((ch & 63) >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2) = o;
+                }
+            }
+    }
+    // ---- phases 2 + 3, one 64-channel chunk of the block output at a time
+    f32x16 acc3[NEXT ? TC : 1][NEXT ? TMT : 1];
+    if (NEXT) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TMT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.0f;
+    }
+    const int a2_row = ((wave / W2M) * W2TC + l31) * 128, b2_row = ((wave % W2M) * W2TM + l31) * 128;
+    for (int oc = 0; oc < NOC; ++oc) {
+        // S0: the residual rows of this chunk -> stage (they were requested one chunk ago); a' weights of this chunk on their way
+#pragma unroll
+        for (int d = 0; d < XL; ++d) *(half8*)(stage + (rb + 32 * d) * 128 + pc * 16) = resv[d];
+        dma_wt3(oc);
+        bar_vm<N3>();   // S1: Wt2(oc) has landed (issued before Wt3), the residual and (chunk 0) Bt are visible
+        // S2: chunk GEMM  acc2[64 ch][TM] = W_c[oc*64 .. +63][:] x b
+        f32x16 acc2[TC2][TMT2];
+#pragma unroll
+        for (int i = 0; i < TC2; ++i)
+#pragma unroll
+            for (int j = 0; j < TMT2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((2 * kk + lh) ^ swz) << 4;
+                half8 fa[TC2], fb[TMT2];
+#pragma unroll
+                for (int i = 0; i < TC2; ++i) fa[i] = *(const half8*)(wt2 + kt * 8192 + a2_row + i * 4096 + co);
+#pragma unroll
+                for (int j = 0; j < TMT2; ++j) fb[j] = *(const half8*)(bt + kt * (TM * 128) + b2_row + j * 4096 + co);
+#pragma unroll
+                for (int i = 0; i < TC2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
+            }
+        // S3: request the next chunk's residual rows (in flight until the next S0)
+        if (oc + 1 < NOC) load_res(oc + 1);
+        // S4: y chunk = relu(acc2 + bias_c + x), rounded, in place over the residual in stage (one lane per element)
+#pragma unroll
+        for (int i = 0; i < TC2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (wave / W2M) * W2TC + i * 32 + 8 * g + 4 * lh;   // channel within the chunk
+                const f32x4 b4 = *(const f32x4*)(p.bias3 + oc * 64 + ch);
+#pragma unroll
+                for (int j = 0; j < TMT2; ++j) {
+                    const int m = (wave % W2M) * W2TM + j * 32 + l31;
+                    half4* const q = (half4*)(stage + m * 128 + (((ch >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2);
+                    const half4 r4 = *q;
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[i][j][4 * g + e] + b4[e];
+                        v = v + (float)r4[e];
+                        o[e] = (half_t)fmaxf(v, 0.0f);
+                    }
+                    *q = o;
+                }
+            }
+        // S5: the y chunk is complete; Wt3(oc) has landed (only the residual loads of S3 may still be in flight)
+        if (oc + 1 < NOC) bar_vm<XL>(); else bar_vm<0>();
+        // S6: whole-row stores of the y chunk; the next chunk's expand weights; a' += W_a'[:, chunk] x y chunk
+#pragma unroll
+        for (int d = 0; d < XL; ++d) {
+            const int m = m0 + rb + 32 * d;
+            if (m < p.M) *(half8*)(p.y + (long long)m * C4 + oc * 64 + lc * 8) = *(const half8*)(stage + (rb + 32 * d) * 128 + pc * 16);
+        }
+        if (oc + 1 < NOC) dma_wt2(oc + 1);
+        if (NEXT) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((2 * kk + lh) ^ swz) << 4;
+                half8 fa[TC], fb[TMT];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) fa[i] = *(const half8*)(wt3 + a1_row + i * 4096 + co);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) fb[j] = *(const half8*)(stage + b1_row + j * 4096 + co);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j) acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc3[i][j], 0, 0, 0);
+            }
+        }
+        // S7: everyone is done with stage, Wt2 is refilled behind this barrier's successor S1 (counted), Wt3 is free
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (!NEXT) return;
+    // ---- a' = relu(acc3 + bias_a'), rounded, through Bt (dead: [KT][TM][128 B], the layout of a PL-channel row set), whole-row stores
+    {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (wave / WM) * WTC + i * 32 + 8 * g + 4 * lh;
+                const f32x4 b4 = *(const f32x4*)(p.bias1n + ch);
+#pragma unroll
+                for (int j = 0; j < TMT; ++j) {
+                    const int m = (wave % WM) * WTM + j * 32 + l31;
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf(acc3[i][j][4 * g + e] + b4[e], 0.0f);
+                    *(half4*)(bt + (ch >> 6) * (TM * 128) + m * 128 + ((((ch & 63) >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2) = o;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int d = 0; d < XL; ++d) {
+                const int m = m0 + rb + 32 * d;
+                if (m < p.M) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = *(const half8*)(bt + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
+            }
+    }
+}
+
+const char* bneck_symbol(int planes, int tm, bool next) {
+    if (planes == 64 && tm == 128) return next ? "bneck_chain_f16<64,128,next>" : "bneck_chain_f16<64,128>";
+    if (planes == 64) return tm == 256 ? (next ? "bneck_chain_f16<64,256,next>" : "bneck_chain_f16<64,256>") : (next ? "bneck_chain_f16<64,64,next>" : "bneck_chain_f16<64,64>");
+    return tm == 128 ? (next ? "bneck_chain_f16<128,128,next>" : "bneck_chain_f16<128,128>") : (next ? "bneck_chain_f16<128,64,next>" : "bneck_chain_f16<128,64>");
+}
+
+// planes in {64, 128}; tm: 256 / 64 for 64 planes, 128 / 64 for 128 planes (the small tiles for launches that would leave CUs idle)
+hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream) {
+    if (p.M < 1 || (p.stride != 1 && p.stride != 2)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((p.M + tm - 1) / tm));
+    const bool next = p.a_next != nullptr;
+    if (planes == 64 && tm == 256) {
+        if (next) hipLaunchKernelGGL((bneck_chain_f16<64, 256, 1, 4, 1, 4, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bneck_chain_f16<64, 256, 1, 4, 1, 4, false>), grid, dim3(256), 0, stream, p);
+    } else if (planes == 64 && tm == 128) {
+        if (next) hipLaunchKernelGGL((bneck_chain_f16<64, 128, 1, 4, 1, 4, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bneck_chain_f16<64, 128, 1, 4, 1, 4, false>), grid, dim3(256), 0, stream, p);
+    } else if (planes == 64 && tm == 64) {
+        if (next) hipLaunchKernelGGL((bneck_chain_f16<64, 64, 2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bneck_chain_f16<64, 64, 2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
+    } else if (planes == 128 && tm == 128) {
+        if (next) hipLaunchKernelGGL((bneck_chain_f16<128, 128, 2, 2, 1, 4, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bneck_chain_f16<128, 128, 2, 2, 1, 4, false>), grid, dim3(256), 0, stream, p);
+    } else if (planes == 128 && tm == 64) {
+        if (next) hipLaunchKernelGGL((bneck_chain_f16<128, 64, 2, 2, 2, 2, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bneck_chain_f16<128, 64, 2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace yh

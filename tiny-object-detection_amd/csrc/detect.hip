@@ -204,7 +204,13 @@ __global__ __launch_bounds__(256) void det_class_nms(const DetectParams p) {
     const int list = blockIdx.x;  // b*(C-1) + c
     const int b = list / (p.C - 1);
     const int tid = threadIdx.x;
-    const int nc = p.cls_count[list];
+    // This workgroup is the one consumer of its list's candidate counter: it takes the count and leaves the counter zero for
+    // the next step, so that no memset node is needed in front of K1 (a captured step then consists of kernel nodes only:
+    // profiles/r03_fault_audit.md). yh_create zeroes the counters once.
+    __shared__ int sh_nc;
+    if (tid == 0) { sh_nc = p.cls_count[list]; p.cls_count[list] = 0; }
+    __syncthreads();
+    const int nc = sh_nc;
     const uint2* cand = p.cand + (long long)list * p.P;
     const int K = nc < p.top_k ? nc : p.top_k;
     const long long so = (long long)list * p.top_k;
@@ -388,33 +394,31 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     }
 }
 
-int detect_launch_count() { return 5; }
+int detect_launch_count() { return 4; }
 
 const char* detect_stage_name(int stage) {
-    static const char* n[5] = { "hipMemsetAsync:det_counts", "det_softmax_cand:tail", "det_class_nms:tail",
-                                "det_frame_top:tail", "det_masks:tail" };
-    return stage >= 0 && stage < 5 ? n[stage] : "?";
+    static const char* n[4] = { "det_softmax_cand:tail", "det_class_nms:tail", "det_frame_top:tail", "det_masks:tail" };
+    return stage >= 0 && stage < 4 ? n[stage] : "?";
 }
 
 hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) {
     switch (stage) {
-        case 0: return hipMemsetAsync(p.cls_count, 0, sizeof(int) * (size_t)p.n * (p.C - 1), s);
-        case 1: {
+        case 0: {   // (the candidate counters are zero on entry: K2 re-zeroes what it consumes)
             const dim3 grid((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n);
             if (p.C == 81 && !p.k1_generic) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
             else hipLaunchKernelGGL(det_softmax_cand, grid, dim3(192), (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }
-        case 2: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(det_frame_top, dim3((unsigned)p.n), dim3(1024), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(det_frame_top, dim3((unsigned)p.n), dim3(1024), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_detect(const DetectParams& p, hipStream_t s) {
-    for (int st = 0; st < 5; ++st) {
+    for (int st = 0; st < 4; ++st) {
         hipError_t e = launch_detect_stage(p, st, s);
         if (e != hipSuccess) return e;
     }

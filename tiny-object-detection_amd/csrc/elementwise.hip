@@ -236,4 +236,10 @@ hipError_t launch_cells_f32(const half_t* heads, int n, int cells_img, int cells
     return hipGetLastError();
 }
 
+__global__ void side_touch(unsigned* w) { *w = 0u; }
+hipError_t launch_side_touch(unsigned* w, hipStream_t s) {
+    hipLaunchKernelGGL(side_touch, dim3(1), dim3(1), 0, s, w);
+    return hipGetLastError();
+}
+
 }  // namespace yh

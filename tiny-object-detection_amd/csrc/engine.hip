@@ -83,6 +83,9 @@ struct Op {
     bool has_res = false;
     bool res_up = false;   // the residual is the bilinear resize of the lower-resolution tensor `res` (ConvParams::res_up)
     int tail_op = -1;      // index of the 1x1 conv that may run in this conv's epilogue (ConvParams::w2) when the launch plan allows
+    // bottleneck chain (bneck.hip; tune.chain): on an identity block's 3x3 conv - the block's last 1x1 conv and (if any) the next
+    // block's first 1x1 conv that run inside its launch; on those two - the 3x3 conv that absorbs them
+    int chain_c = -1, chain_a = -1, in_chain = -1;
     int fused_into = -1;   // ... and on that 1x1 conv: the index of the conv that may absorb it
     bool side = false;     // may run on the second stream: nothing on the main stream reads its output before the step's join
     bool dual = false;     // two-source 1x1 form: K continues over `in2` read at `stride2` (ConvParams::x2)
@@ -123,7 +126,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -135,6 +138,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
+    r.chain = d(t.chain, 1);
     return r;
 }
 
@@ -422,6 +426,8 @@ int build_graph_spec(yh_engine* h) {
     }
     Buf x = pool, cfeat[4];
     char nm[32];
+    struct BlockOps { int a, b, c, stage, planes; bool identity; };
+    std::vector<BlockOps> blocks;
     // tune.dsfuse (default): a stage's first block evaluates its projection shortcut inside its last 1x1 conv (two-source
     // form) - the projected tensor is never written or re-read; engines with debug_tensors = 1 keep the two convs so that
     // "l<L>b0_d" can be read.
@@ -432,11 +438,14 @@ int build_graph_spec(yh_engine* h) {
             const int stride = (b == 0 && L > 0) ? 2 : 1;
             const int ho = out_dim(x.h, 3, stride, 1);
             Buf a, bt, y, dn;
+            BlockOps bo{ 0, 0, 0, L, planes, b > 0 };
             snprintf(nm, sizeof nm, "l%db%d_a", L + 1, b);
             if ((rc = new_buf(h, nm, x.h, x.w, planes, &a))) return rc;
+            bo.a = (int)h->ops.size();
             h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), x, a, 1, 0, 1, nullptr));
             snprintf(nm, sizeof nm, "l%db%d_b", L + 1, b);
             if ((rc = new_buf(h, nm, ho, ho, planes, &bt))) return rc;
+            bo.b = (int)h->ops.size();
             h->ops.push_back(conv_op(h, nm, add_panel(h, { ci++ }), a, bt, stride, 1, 1, nullptr));
             const int ci3 = ci++;
             Buf resb = x;
@@ -454,7 +463,9 @@ int build_graph_spec(yh_engine* h) {
                 o.flops_per_img = 2.0 * o.P * o.Q * (planes * 4.0) * (planes + x.c);
                 o.bytes_per_img = 2.0 * ((double)o.P * o.Q * (planes + x.c) + (double)o.P * o.Q * planes * 4);
                 o.bytes_fixed = 2.0 * planes * 4.0 * (planes + x.c);
+                bo.c = (int)h->ops.size();
                 h->ops.push_back(o);
+                blocks.push_back(bo);
                 x = y;
                 continue;
             }
@@ -468,10 +479,26 @@ int build_graph_spec(yh_engine* h) {
             if (last) snprintf(nm, sizeof nm, "c%d", L + 2);
             else snprintf(nm, sizeof nm, "l%db%d", L + 1, b);
             if ((rc = new_buf(h, nm, ho, ho, planes * 4, &y))) return rc;
+            bo.c = (int)h->ops.size();
             h->ops.push_back(conv_op(h, nm, add_panel(h, { ci3 }), bt, y, 1, 0, 1, &resb));
+            blocks.push_back(bo);
             x = y;
         }
         cfeat[L] = x;
+    }
+    // Bottleneck chains (bneck.hip; tune.chain): an identity block of layer 1 or 2 (64 / 128 planes) runs its 3x3 conv, its
+    // last 1x1 conv + residual and - where the next block belongs to the same stage - that block's first 1x1 conv as ONE
+    // launch. Which launches really fuse is decided per batch size (chain_active): the links only say what may.
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        const BlockOps& bo = blocks[i];
+        if (!bo.identity || (bo.planes != 64 && bo.planes != 128)) continue;
+        Op& ob = h->ops[bo.b];
+        ob.chain_c = bo.c;
+        h->ops[bo.c].in_chain = bo.b;
+        if (i + 1 < blocks.size() && blocks[i + 1].stage == bo.stage) {
+            ob.chain_a = blocks[i + 1].a;
+            h->ops[blocks[i + 1].a].in_chain = bo.b;
+        }
     }
     // ---- FPN
     for (int l = 0; l < 5; ++l) h->lvl[l] = l == 0 ? cfeat[1].h : out_dim(h->lvl[l - 1], 3, 2, 1);
@@ -714,6 +741,8 @@ int alloc_tail(yh_engine* h) {
     d.top_k = h->cfg.top_k; d.max_dets = h->cfg.max_dets;
     d.conf_thresh = h->cfg.conf_thresh; d.nms_thresh = h->cfg.nms_thresh;
     d.k1_generic = h->tune.k1_generic;
+    // the candidate counters start at zero and every consumer (det_class_nms) leaves its own at zero again
+    if (hipMemset(d.cls_count, 0, sizeof(int) * (size_t)N * Cf) != hipSuccess) return h->fail(YH_EHIP, "hipMemset tail counters");
     return YH_OK;
 }
 
@@ -976,9 +1005,62 @@ bool conv_absorbed(yh_engine* h, const Op& o, int n) {
     return fill_conv_params(h, h->ops[o.fused_into], n, &p) == YH_OK && p.w2 != nullptr;
 }
 
+// Does the bottleneck chain headed by the 3x3 conv `ob` run as one launch at batch n? (f16 tensors only, dense rows, not when
+// every intermediate must be materialised for yh_debug_read_tensor.)
+bool chain_active(const yh_engine* h, const Op& ob, int n) {
+    if (!h->tune.chain || h->cfg.debug_tensors || ob.chain_c < 0 || n < 1) return false;
+    const Op& oc = h->ops[ob.chain_c];
+    const int planes = h->panels[ob.panel].cout;
+    if ((planes != 64 && planes != 128) || ob.stride != 1 || ob.in.c != planes || oc.out.c != 4 * planes || !oc.has_res || oc.res_up || oc.dual || oc.res.c != 4 * planes) return false;
+    const long long pq = (long long)ob.P * ob.Q;
+    if (oc.out.img_stride != pq * oc.out.c || oc.res.img_stride != pq * oc.res.c) return false;
+    if (h->fp8_active && (ob.write_q || oc.write_q || !oc.write_f16)) return false;
+    if (ob.chain_a >= 0) {
+        const Op& oa = h->ops[ob.chain_a];
+        if (oa.out.c != planes || oa.out.img_stride != pq * planes || (h->fp8_active && (oa.write_q || !oa.write_f16))) return false;
+    }
+    return true;
+}
+int chain_tile_m(const yh_engine* h, const Op& ob, int n) {
+    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? (h->tune.chain == 2 ? 128 : 256) : 128;   // (tune.chain = 2: A/B of the 64-plane tile)
+    const long long M = (long long)n * ob.P * ob.Q;
+    return (M + big - 1) / big >= 2ll * h->tune.plan_cus ? big : 64;   // two workgroups per CU: below that, four times the tiles
+}
+int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
+    const Op& oc = h->ops[ob.chain_c];
+    const Panel &pb = h->panels[ob.panel], &pcn = h->panels[oc.panel];
+    BneckParams p;
+    memset(&p, 0, sizeof p);
+    const long long zo = (const char*)ob.in.zero - (const char*)ob.in.d;
+    if (zo < 0 || zo >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+    p.a = ob.in.d; p.a_zero_off = (unsigned)zo; p.a_bytes = (unsigned)zo + 16u; p.a_img_stride = ob.in.img_stride;
+    p.N = n; p.H = ob.in.h; p.W = ob.in.w; p.P = ob.P; p.Q = ob.Q; p.stride = ob.stride; p.M = n * ob.P * ob.Q;
+    p.w2 = pb.w; p.w2_bytes = (unsigned)((size_t)pb.coutPad * pb.Kpad * 2); p.bias2 = pb.bias;
+    p.w3 = pcn.w; p.w3_bytes = (unsigned)((size_t)pcn.coutPad * pcn.Kpad * 2); p.bias3 = pcn.bias;
+    p.res = oc.res.d; p.y = oc.out.d;
+    if (pb.Kpad != 9 * pb.cout || pcn.Kpad != pb.cout || pcn.cout != 4 * pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: panel geometry mismatch at " + ob.name);
+    if (ob.chain_a >= 0) {
+        const Op& oa = h->ops[ob.chain_a];
+        const Panel& pa = h->panels[oa.panel];
+        if (pa.Kpad != 4 * pb.cout || pa.cout != pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: next conv geometry mismatch at " + oa.name);
+        p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias; p.a_next = oa.out.d;
+    }
+    *out = p;
+    return YH_OK;
+}
+
 int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
     hipError_t e = hipSuccess;
     if (o.kind == OP_CONV && conv_absorbed(h, o, n)) return YH_OK;
+    if (o.kind == OP_CONV && o.in_chain >= 0 && chain_active(h, h->ops[o.in_chain], n)) return YH_OK;   // runs inside the chain's launch
+    if (o.kind == OP_CONV && chain_active(h, o, n)) {
+        BneckParams bp;
+        const int rc = fill_bneck_params(h, o, n, &bp);
+        if (rc) return rc;
+        e = launch_bneck(bp, h->panels[o.panel].cout, chain_tile_m(h, o, n), side ? h->side : h->stream);
+        if (e != hipSuccess) return h->fail(YH_EHIP, "bneck_chain_f16:" + o.name + ": " + hipGetErrorString(e));
+        return YH_OK;
+    }
     if (side && o.kind != OP_CONV) return h->fail(YH_EINVAL, "only convolutions fork onto the side stream");
     switch (o.kind) {
         case OP_PRE:
@@ -1045,7 +1127,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     if (dummy_branch) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        HIPCHK(h, hipMemsetAsync(h->side_word, 0, 4, h->side));
+        if (launch_side_touch(h->side_word, h->side) != hipSuccess) return h->fail(YH_EHIP, "side branch launch failed");   // (a kernel node, not a memset node)
         HIPCHK(h, hipEventRecord(h->ev_join, h->side));
     }
     // Ops tagged `side` (the FPN's P4..P7 convolutions and the prediction head: nothing on the main stream reads them before
@@ -1067,7 +1149,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
             // the tail's K1-K3 follow the head on the side stream (or fork there now, behind a head that ran on the main stream)
             if (!prev_side) { const int rc = fork_to_side(); if (rc) return rc; }
             h->det.n = n;
-            for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 3; ++st)   // K1 softmax / candidates, K2 per-class top-k + Fast-NMS, K3 frame top-k
                 if (launch_detect_stage(h->det, st, h->side) != hipSuccess) return h->fail(YH_EHIP, "detect stage launch failed");
             tail_forked = true;
             prev_side = false;
@@ -1085,7 +1167,7 @@ int enqueue_all(yh_engine* h, int n, int with_tail) {
     if (with_tail) {
         TraceRange tr_tail("yh:tail(enqueue)");
         h->det.n = n;
-        const hipError_t e = tail_forked ? launch_detect_stage(h->det, 4, h->stream)   // masks: need the prototypes too
+        const hipError_t e = tail_forked ? launch_detect_stage(h->det, 3, h->stream)   // masks: need the prototypes too
                                          : launch_detect(h->det, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, std::string("detect: ") + hipGetErrorString(e));
     }
@@ -1140,7 +1222,11 @@ int run(yh_engine* h, int with_tail) {
     const int n = h->cur_n;
     int rc = wait_input(h);
     if (rc) return rc;
-    if (!h->cfg.use_graph) return enqueue_all(h, n, with_tail);
+    if (!h->cfg.use_graph) {
+        rc = enqueue_all(h, n, with_tail);
+        if (rc) { hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side); hipMemset(h->det.cls_count, 0, sizeof(int) * (size_t)h->cfg.max_batch * (h->C - 1)); }
+        return rc;
+    }
     const int key = (n * 2 + (with_tail ? 1 : 0)) * 2 + h->in_cur;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
@@ -1454,7 +1540,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
-    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3;
+    out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
     return YH_OK;
 }
 
@@ -2000,8 +2086,10 @@ const uint32_t* yh_classify_device_frame(const yh_engine* h) { return h ? h->fra
 // Is `name` the output of a conv whose 1x1 tail ran in its epilogue at the current batch size (the tensor was not written)?
 static bool absorbed_output(yh_engine* h, const char* name) {
     if (h->cur_n < 1) return false;
-    for (const Op& o : h->ops)
+    for (const Op& o : h->ops) {
         if (o.kind == OP_CONV && o.tail_op >= 0 && o.name == name) return conv_absorbed(h, h->ops[o.tail_op], h->cur_n);
+        if (o.kind == OP_CONV && o.chain_c >= 0 && o.name == name) return chain_active(h, o, h->cur_n);   // b stays in LDS
+    }
     return false;
 }
 
@@ -2188,6 +2276,8 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         const Op& o = h->ops[i];
         if (o.kind != OP_CONV) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }
         if (conv_absorbed(h, o, n)) continue;   // (accounted with the launch that computes it)
+        if (o.in_chain >= 0 && chain_active(h, h->ops[o.in_chain], n)) continue;
+        if (chain_active(h, o, n)) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }   // one launch: launch_op
         ConvParams p;
         ConvTile tile;
         const int rc = fill_conv_params(h, o, n, &p, &tile);
@@ -2262,6 +2352,20 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                     h->prof_labels[i] += "+" + t.name;
                     fl += t.flops_per_img * n;
                     by += t.bytes_fixed + 2.0 * n * ((double)t.P * t.Q * h->panels[t.panel].cout - (double)o.P * o.Q * h->panels[o.panel].cout * (h->fp8_active && !o.write_f16 ? 0.0 : 1.0));
+                }
+            } else if (o.kind == OP_CONV && chain_active(h, o, n)) {
+                // a bottleneck chain: the FLOPs of its two or three convolutions; HBM bytes = a + residual in, y (+ a') out, the weights
+                const Op& oc = h->ops[o.chain_c];
+                const int planes = h->panels[o.panel].cout;
+                const double px = (double)n * o.P * o.Q;
+                h->prof_labels[i] = std::string(bneck_symbol(planes, chain_tile_m(h, o, n), o.chain_a >= 0)) + ":" + o.name + "+" + oc.name;
+                fl += oc.flops_per_img * n;
+                by = 2.0 * ((double)n * o.in.h * o.in.w * planes + px * 4.0 * planes * 2.0) + o.bytes_fixed + oc.bytes_fixed;
+                if (o.chain_a >= 0) {
+                    const Op& oa = h->ops[o.chain_a];
+                    h->prof_labels[i] += "+" + oa.name;
+                    fl += oa.flops_per_img * n;
+                    by += 2.0 * px * planes + oa.bytes_fixed;
                 }
             } else h->prof_labels[i] = o.label;
         } else h->prof_labels[i] = detect_stage_name(pe.stage);

@@ -560,7 +560,7 @@ int run_plan(yh_tfl* h) {
         // a second branch: the runtime then replays the graph node by node (see above)
         step(hipEventRecord(h->ev_fork, h->stream), "fork record");
         step(hipStreamWaitEvent(h->side, h->ev_fork, 0), "fork wait");
-        step(hipMemsetAsync(h->side_word, 0, 4, h->side), "side memset");
+        step(launch_side_touch((unsigned*)h->side_word, h->side), "side branch");   // (a kernel node: no memset node in any capture)
         step(hipEventRecord(h->ev_join, h->side), "join record");
         const int rc = ce == hipSuccess ? enqueue_plan(h) : YH_OK;
         step(hipStreamWaitEvent(h->stream, h->ev_join, 0), "join wait");   // (also after a failed enqueue: an unjoined fork invalidates the capture)

@@ -103,6 +103,29 @@ const char* conv_tile_symbol(ConvTile t);
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
 hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream);
 
+// A bottleneck block's 3x3 conv, its 1x1 expand conv with the residual add, and the NEXT block's 1x1 reduce conv as one
+// kernel (bneck.hip): b stays in LDS, y and a' are written once. planes in {64, 128}.
+struct BneckParams {
+    const half_t* a;        // [N][H][W][planes]: the block's conv_a output
+    unsigned a_bytes, a_zero_off;   // buffer-descriptor range of a (includes the allocation's zero block) and that block's offset
+    long long a_img_stride;
+    int N, H, W, P, Q, stride, M;   // 3x3, pad 1; M = N * P * Q
+    const half_t* w2;       // [planes][9 planes], K index = (r * 3 + s) * planes + c
+    unsigned w2_bytes;
+    const float* bias2;     // [planes]
+    const half_t* w3;       // [4 planes][planes]
+    unsigned w3_bytes;
+    const float* bias3;     // [4 planes]
+    const half_t* res;      // [M][4 planes] dense: the block input (identity shortcut)
+    half_t* y;              // [M][4 planes] dense: the block output
+    const half_t* w1n;      // [planes][4 planes]: the next block's conv_a (nullptr: none)
+    unsigned w1n_bytes;
+    const float* bias1n;    // [planes]
+    half_t* a_next;         // [M][planes] dense (nullptr: none)
+};
+hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream);
+const char* bneck_symbol(int planes, int tm, bool next);
+
 // Fused stem: 7x7 stride-2 conv (3 -> 64 channels, bias, ReLU) + 3x3 stride-2 max pool, one kernel.
 struct StemPoolParams {
     const half_t* x;      // [n][Hp][Wp][4] f16, image at (+3, +3) inside a zero border (preprocess_rgb8_f16)
@@ -141,6 +164,8 @@ hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, in
                               float* conf, float* mask, hipStream_t s);
 hipError_t launch_f16_to_f32(const half_t* x, float* y, long long n, hipStream_t s);
 hipError_t launch_quantize_e4m3(const half_t* x, uint8_t* y, long long n, float inv_scale, hipStream_t s);
+// one lane writes 0 to *w: the one-node second branch of captures that have no fork of their own (engine.hip, enqueue_all)
+hipError_t launch_side_touch(unsigned* w, hipStream_t s);
 hipError_t launch_cells_f32(const half_t* heads, int n, int cells_img, int cells_l0, int ldh, int C,
                             float* out, hipStream_t s);
 

@@ -84,6 +84,22 @@ def main():
             print("only forked:   ", l)
         for l in sorted(sb - sa):
             print("only fork-less:", l)
+    # (iii) every pointer in the captured launch arguments lies inside an allocation of THIS handle (none of an earlier one)
+    import re
+    spans = []
+    for ln in e1.alloc_map().splitlines():
+        t = ln.split()
+        spans.append((int(t[3], 16), int(t[5], 16), t[1]))
+    bad, seen = [], 0
+    for ln in forked.splitlines():
+        for m in re.finditer(r"0x[0-9a-f]{9,}", ln):
+            v = int(m.group(0), 16)
+            seen += 1
+            if not any(b0 <= v < e0 for b0, e0, _ in spans):
+                bad.append((hex(v), ln[:80]))
+    print(f"## (iii) {seen} pointers in the captured launch arguments; outside every allocation of the batch-1 handle: {len(bad)}")
+    for b_ in bad[:20]:
+        print("   ", b_)
     e1.close(); src.close()
 
 
