@@ -105,7 +105,10 @@ typedef struct yh_tuning {
                               * layers and the 64- / 128-channel 3x3 layers */
     int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
     int32_t chain;           /* identity bottleneck blocks of layers 1-2 as ONE launch each: 3x3 conv + 1x1 expand conv with the residual
-                              * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches; 1) */
+                              * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches). Bit 0
+                              * on (default 1), bit 1 128-pixel tiles for 64 planes, bit 2 one workgroup per tile instead of the
+                              * persistent grid, bit 3 no phase stagger, bit 4 also fuse launches that only fill 64-pixel tiles
+                              * (small batches: slower, a test hook), bits 8.. stagger in units of 4096 clocks */
 } yh_tuning;
 
 typedef struct yh_config {

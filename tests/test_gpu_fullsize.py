@@ -305,7 +305,8 @@ def test_yolact700_r101_one_frame_vs_oracle(built, oracle):
 def test_yolact700_r101_fp8_one_frame_vs_fp8_oracle(built, oracle):
     """The fp8 forward at configs[4]'s geometry against the oracle's fp8 mode with the engine's calibrated scales (bounds
     and their reasons: tests/test_gpu_fp8.py), the tail bit-exact on the engine's heads, and the
-    frame-slot independence of a batch of 3 (the 36 E4M3 launches take the 128 x 128 fp8 tile at this batch size)."""
+    frame-slot independence of a batch of 3 (at this batch size most of the 36 E4M3 launches take the 64 x 64 fp8 tile, the 88 x 88
+    and 176 x 176 layers the 128 x 128 one; every tile, layer by layer on identical inputs: tests/test_gpu_fp8_sweep.py)."""
     import yolact_amd as ya
     S7 = 700
     eng = ya.Engine(input_size=S7, backbone=101, max_batch=3, use_graph=True, precision=ya.PRECISION_FP8)

@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     char* const stage = lds + A_BYTES;
     char* const wt3 = lds + A_BYTES + ST_BYTES;
 
-    // XCD-aware bijective remap of the tile id (conv_igemm.hip)
+    // Persistent grid: workgroup w walks tiles w, w + grid, ... The workgroups that share a CU run the same program: started
+    // together they stay in lockstep (both in the MFMA / L2-bound 3x3 phase, then both in the HBM-bound expand phase) and the
+    // kernel takes the SUM of the two phases. The second-dispatched half of the grid therefore starts p.stagger sleep units
+    // (64 clocks each) late - once -, which puts the co-resident workgroups in opposite phases for the rest of the launch
+    // (which workgroups share a CU is the dispatcher's business: a wrong guess costs the delay, never correctness).
     const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = tile * TM;
+    if (p.stagger > 0 && bid >= (nwg >> 1))
+        for (int t = 0; t < p.stagger; t += 127) __builtin_amdgcn_s_sleep(127);
+    const int ntiles = (p.M + TM - 1) / TM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pc = tid & 7, rb = tid >> 3;          // DMA / row-pass role: physical chunk pc of rows rb + 32 d
@@ -95,6 +99,8 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? p.w1n : p.w3), 0, (int)(NEXT ? p.w1n_bytes : 0u), 0x00020000);
 
+    for (int tile = bid; tile < ntiles; tile += nwg) {
+    const int m0 = tile * TM;
     // ---- residual rows of chunk oc -> registers (16 bytes per lane and pass: rows rb + 32 d, logical chunk lc)
     half8 resv[XL];
     auto load_res = [&](int oc) {
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (!NEXT) return;
+    if (NEXT) {
     // ---- a' = relu(acc3 + bias_a'), rounded, through Bt (dead: [KT][TM][128 B], the layout of a PL-channel row set), whole-row stores
     {
 #pragma unroll
@@ -316,6 +322,9 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
                 if (m < p.M) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = *(const half8*)(bt + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
             }
     }
+    }
+    __syncthreads();   // the next tile's phase 1 reuses region A
+    }   // persistent tile loop
 }
 
 const char* bneck_symbol(int planes, int tm, bool next) {
@@ -327,7 +336,9 @@ const char* bneck_symbol(int planes, int tm, bool next) {
 // planes in {64, 128}; tm: 256 / 64 for 64 planes, 128 / 64 for 128 planes (the small tiles for launches that would leave CUs idle)
 hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream) {
     if (p.M < 1 || (p.stride != 1 && p.stride != 2)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((p.M + tm - 1) / tm));
+    const int ntiles = (p.M + tm - 1) / tm;
+    const int slots = p.grid_cap > 0 ? p.grid_cap : ntiles;
+    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     const bool next = p.a_next != nullptr;
     if (planes == 64 && tm == 256) {
         if (next) hipLaunchKernelGGL((bneck_chain_f16<64, 256, 1, 4, 1, 4, true>), grid, dim3(256), 0, stream, p);

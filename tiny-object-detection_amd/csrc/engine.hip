@@ -1007,8 +1007,12 @@ bool conv_absorbed(yh_engine* h, const Op& o, int n) {
 
 // Does the bottleneck chain headed by the 3x3 conv `ob` run as one launch at batch n? (f16 tensors only, dense rows, not when
 // every intermediate must be materialised for yh_debug_read_tensor.)
+int chain_tile_m(const yh_engine* h, const Op& ob, int n);
 bool chain_active(const yh_engine* h, const Op& ob, int n) {
-    if (!h->tune.chain || h->cfg.debug_tensors || ob.chain_c < 0 || n < 1) return false;
+    if (!(h->tune.chain & 1) || h->cfg.debug_tensors || ob.chain_c < 0 || n < 1) return false;
+    // Launches too small for two big tiles per CU stay separate: with few, long-lived workgroups the serial chain is slower than
+    // three short launches (batch 1: 0.723 vs 0.711 ms per step with 64-pixel tiles). tune.chain bit 4 fuses them anyway (tests).
+    if (chain_tile_m(h, ob, n) == 64 && !(h->tune.chain & 16)) return false;
     const Op& oc = h->ops[ob.chain_c];
     const int planes = h->panels[ob.panel].cout;
     if ((planes != 64 && planes != 128) || ob.stride != 1 || ob.in.c != planes || oc.out.c != 4 * planes || !oc.has_res || oc.res_up || oc.dual || oc.res.c != 4 * planes) return false;
@@ -1022,7 +1026,7 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
     return true;
 }
 int chain_tile_m(const yh_engine* h, const Op& ob, int n) {
-    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? (h->tune.chain == 2 ? 128 : 256) : 128;   // (tune.chain = 2: A/B of the 64-plane tile)
+    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? ((h->tune.chain & 2) ? 128 : 256) : 128;   // (tune.chain bit 1: A/B of the 64-plane tile)
     const long long M = (long long)n * ob.P * ob.Q;
     return (M + big - 1) / big >= 2ll * h->tune.plan_cus ? big : 64;   // two workgroups per CU: below that, four times the tiles
 }
@@ -1045,6 +1049,10 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
         if (pa.Kpad != 4 * pb.cout || pa.cout != pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: next conv geometry mismatch at " + oa.name);
         p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias; p.a_next = oa.out.d;
     }
+    // persistent grid, two workgroups per CU, the second half started half a tile late (bneck.hip); A/B: tune.chain bit 2 = one
+    // workgroup per tile, bit 3 = no stagger
+    if (!(h->tune.chain & 4)) p.grid_cap = 2 * h->tune.plan_cus;
+    if (!(h->tune.chain & 8) && p.grid_cap > 0) p.stagger = (h->tune.chain >> 8) ? (h->tune.chain >> 8) * 64 : 704;   // ~21 us at 2.1 GHz: half a tile
     *out = p;
     return YH_OK;
 }

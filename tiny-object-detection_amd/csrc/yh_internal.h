@@ -122,6 +122,8 @@ struct BneckParams {
     unsigned w1n_bytes;
     const float* bias1n;    // [planes]
     half_t* a_next;         // [M][planes] dense (nullptr: none)
+    int grid_cap;           // > 0: persistent grid of at most this many workgroups (each walks its tiles); 0: one workgroup per tile
+    int stagger;            // > 0: the second-dispatched half of the grid starts this many 64-clock sleep units late (phase offset)
 };
 hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream);
 const char* bneck_symbol(int planes, int tm, bool next);
