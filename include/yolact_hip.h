@@ -106,9 +106,10 @@ typedef struct yh_tuning {
     int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
     int32_t chain;           /* identity bottleneck blocks of layers 1-2 as ONE launch each: 3x3 conv + 1x1 expand conv with the residual
                               * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches). Bit 0
-                              * on (default 1), bit 1 128-pixel tiles for 64 planes, bit 2 one workgroup per tile instead of the
-                              * persistent grid, bit 3 no phase stagger, bit 4 also fuse launches that only fill 64-pixel tiles
-                              * (small batches: slower, a test hook), bits 8.. stagger in units of 4096 clocks */
+                              * on (default 1), bit 1 128-pixel tiles for 64 planes, bit 2 a persistent grid (two workgroups per CU) instead
+                              * of one workgroup per tile, bit 3 (with bit 2) a phase stagger between co-resident workgroups, bit 4
+                              * also fuse launches that only fill 64-pixel tiles (small batches: slower, a test hook), bits 8..
+                              * the stagger in units of 4096 clocks. Bits 1-3 are measured A/B forms, all slower than the default */
 } yh_tuning;
 
 typedef struct yh_config {
@@ -126,7 +127,10 @@ typedef struct yh_config {
     int32_t debug_tensors; /* 1: also materialise tensors that production runs fuse away (the pre-pool
                             * "stem" tensor, the bilinear upsamples) for yh_debug_read_tensor; 0 (default): do not */
     int32_t precision;     /* YH_PRECISION_F16 (default) | YH_PRECISION_FP8 */
-    int32_t reserved[6];   /* zero */
+    int32_t fp8_f16_layers;/* YH_PRECISION_FP8 only: groups of the K-heavy 3x3 layers that stay f16 (a hybrid: accuracy for speed, DESIGN.md
+                            * §10 table): bit 0 the shared head trunk, bit 1 the protonet (proto0..3), bit 2 the FPN's pred / down convs
+                            * (p3..p7), bit 3 the backbone (layers 3-4). 0 (default): all 36 of YOLACT-700 R101 run fp8 */
+    int32_t reserved[5];   /* zero */
     yh_tuning tune;        /* yh_default_config sets every field to -1 */
 } yh_config;
 

@@ -23,8 +23,8 @@ def _pair(ya, n, **tune):
 @pytest.mark.parametrize("n,tune,want", [
     (1, {"chain": 17}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64"}),            # batch 1: the small tiles (test hook: bit 4)
     (8, {"chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64"}),           # 595 big tiles in layer 1, 298 in layer 2
-    (8, {"plan_cus": 64}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),       # planned for a 64-CU chip: both big tiles, persistent + staggered
-    (8, {"plan_cus": 64, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),   # one workgroup per tile, no stagger
+    (8, {"plan_cus": 64}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),       # planned for a 64-CU chip: both big tiles, one workgroup per tile
+    (8, {"plan_cus": 64, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),   # persistent grid + phase stagger (A/B forms)
     (8, {"plan_cus": 64, "chain": 3}, {"bneck_chain_f16<64,128"}),                     # the 128-pixel form of the 64-plane tile
 ])
 def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want):
@@ -58,7 +58,7 @@ def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want):
 def test_chain_layers_against_the_oracle(built, oracle):
     """... and not only against the library's own other path: block outputs of a fused batch-2 run against the oracle's forward."""
     import yolact_amd as ya
-    eng = ya.Engine(input_size=S, max_batch=2, use_graph=True)
+    eng = ya.Engine(input_size=S, max_batch=2, use_graph=True, tune=dict(chain=17))   # (batch 2 only fills the 64-pixel tiles: bit 4)
     blob = eng.generate_weights(seed=1)
     eng.load_weights(blob)
     frames = np.random.default_rng(9).integers(0, 256, (2, S, S, 3), dtype=np.uint8)

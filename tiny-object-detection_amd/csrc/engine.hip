@@ -655,6 +655,11 @@ void plan_fp8(yh_engine* h) {
         if (o.kind != OP_CONV) continue;
         Panel& pn = h->panels[o.panel];
         const ConvDesc& d0 = h->convs[pn.src[0]];
+        // (yh_config.fp8_f16_layers: groups kept in f16 - bit 0 head trunk, 1 protonet, 2 FPN pred / down, 3 backbone)
+        const int keep = h->cfg.fp8_f16_layers;
+        const bool is_head = o.name.compare(0, 6, "head_t") == 0, is_proto = o.name.compare(0, 5, "proto") == 0, is_bb = o.name[0] == 'l';
+        const bool is_fpn = o.name[0] == 'p' && !is_proto;
+        if (((keep & 1) && is_head) || ((keep & 2) && is_proto) || ((keep & 4) && is_fpn) || ((keep & 8) && is_bb)) continue;
         if (pn.k == 3 && d0.cin % 128 == 0 && d0.cin >= 256 && pn.cout % 256 == 0 && pn.coutPad % 256 == 0 && o.in.q) {
             o.fp8 = true; pn.fp8 = true; pn.in_sid = o.in.sid;
             h->fp8_ops.push_back((int)i);
@@ -1015,6 +1020,7 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
     if (chain_tile_m(h, ob, n) == 64 && !(h->tune.chain & 16)) return false;
     const Op& oc = h->ops[ob.chain_c];
     const int planes = h->panels[ob.panel].cout;
+    if (planes == 128 && (h->tune.chain & 32)) return false;   // (A/B: chains in layer 1 only)
     if ((planes != 64 && planes != 128) || ob.stride != 1 || ob.in.c != planes || oc.out.c != 4 * planes || !oc.has_res || oc.res_up || oc.dual || oc.res.c != 4 * planes) return false;
     const long long pq = (long long)ob.P * ob.Q;
     if (oc.out.img_stride != pq * oc.out.c || oc.res.img_stride != pq * oc.res.c) return false;
@@ -1049,10 +1055,11 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
         if (pa.Kpad != 4 * pb.cout || pa.cout != pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: next conv geometry mismatch at " + oa.name);
         p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias; p.a_next = oa.out.d;
     }
-    // persistent grid, two workgroups per CU, the second half started half a tile late (bneck.hip); A/B: tune.chain bit 2 = one
-    // workgroup per tile, bit 3 = no stagger
-    if (!(h->tune.chain & 4)) p.grid_cap = 2 * h->tune.plan_cus;
-    if (!(h->tune.chain & 8) && p.grid_cap > 0) p.stagger = (h->tune.chain >> 8) ? (h->tune.chain >> 8) * 64 : 704;   // ~21 us at 2.1 GHz: half a tile
+    // One workgroup per tile (measured best: 9.64 ms per batch-64 step against 9.87 unfused). A/B forms kept behind tune.chain:
+    // bit 2 a persistent grid of two workgroups per CU (9.67), bit 3 (with bit 2) the second-dispatched half started late so
+    // that co-resident workgroups sit in opposite phases (9.77: the idle start costs more than the offset buys).
+    if (h->tune.chain & 4) p.grid_cap = 2 * h->tune.plan_cus;
+    if ((h->tune.chain & 8) && p.grid_cap > 0) p.stagger = (h->tune.chain >> 8) ? (h->tune.chain >> 8) * 64 : 704;   // ~21 us at 2.1 GHz: half a tile
     *out = p;
     return YH_OK;
 }
@@ -1428,7 +1435,7 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
         cfg->input_size > 1024 || cfg->max_batch < 1 || cfg->max_batch > 256 || cfg->num_classes < 5 ||
         cfg->num_classes > 81 || cfg->top_k < 1 || cfg->top_k > 256 || cfg->max_dets < 1 || cfg->max_dets > 128 ||
         (cfg->num_classes - 1) * cfg->top_k > 16384 || (cfg->debug_tensors != 0 && cfg->debug_tensors != 1) ||
-        (cfg->precision != YH_PRECISION_F16 && cfg->precision != YH_PRECISION_FP8)) {
+        (cfg->precision != YH_PRECISION_F16 && cfg->precision != YH_PRECISION_FP8) || cfg->fp8_f16_layers < 0 || cfg->fp8_f16_layers > 15) {
         g_create_error = "configuration out of range";
         return YH_EINVAL;
     }

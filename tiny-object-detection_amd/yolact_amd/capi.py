@@ -46,7 +46,7 @@ class Config(C.Structure):
                 ("input_size", C.c_int32), ("max_batch", C.c_int32), ("num_classes", C.c_int32),
                 ("top_k", C.c_int32), ("max_dets", C.c_int32), ("conf_thresh", C.c_float),
                 ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("debug_tensors", C.c_int32),
-                ("precision", C.c_int32), ("reserved", C.c_int32 * 6), ("tune", Tuning)]
+                ("precision", C.c_int32), ("fp8_f16_layers", C.c_int32), ("reserved", C.c_int32 * 5), ("tune", Tuning)]
 
 
 class TensorInfo(C.Structure):
@@ -216,7 +216,7 @@ class Engine:
 
     def __init__(self, input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100,
                  conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0, debug_tensors=False, precision=PRECISION_F16,
-                 tune=None):
+                 tune=None, fp8_f16_layers=0):
         self.L = load_library()
         cfg = Config()
         self.L.yh_default_config(C.byref(cfg))
@@ -225,6 +225,7 @@ class Engine:
         cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = conf_thresh, nms_thresh, 1 if use_graph else 0
         cfg.debug_tensors = 1 if debug_tensors else 0
         cfg.precision = precision
+        cfg.fp8_f16_layers = fp8_f16_layers
         if tune:
             cfg.tune = Tuning.of(**tune)
         self._tune = dict(tune or {})
