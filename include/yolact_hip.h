@@ -354,6 +354,11 @@ const char* yh_tfl_last_error(const yh_tfl* h);
 int yh_tfl_input_info(const yh_tfl* h, yh_tensor_info* info);                 /* inputs()[0], :149-150 */
 int yh_tfl_output_count(const yh_tfl* h);                                      /* outputs(), :166 */
 int yh_tfl_output_info(const yh_tfl* h, int32_t i, yh_tensor_info* info);      /* tensor_info(output), :170-175 */
+/* Images per invoke: 1 (default) or 2 - the model is batch 1 (yolact.rs:149-150), its two tiles per frame are independent
+ * (:216-217) and run as one pass of a batch plan (activations image-major; yh_tfl_classify_frame_u32 does this itself).
+ * yh_tfl_set_input then takes n images, yh_tfl_output_read / yh_tfl_tensor_read return n. YH_EINVAL for a model with an
+ * operator along the image axis. */
+int yh_tfl_set_batch(yh_tfl* h, int32_t n_images);
 int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes);              /* tensor_data_mut copy, :161-162 */
 int yh_tfl_invoke(yh_tfl* h);                                                  /* interpreter.invoke(), :163 */
 int yh_tfl_output_read(yh_tfl* h, int32_t i, void* dst, size_t nbytes);        /* tensor_data::<u8|f32>, :173,:180 */

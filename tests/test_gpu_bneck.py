@@ -22,10 +22,10 @@ def _pair(ya, n, **tune):
 
 @pytest.mark.parametrize("n,tune,want", [
     (1, {"chain": 17}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64"}),            # batch 1: the small tiles (test hook: bit 4)
-    (8, {"chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64"}),           # 595 big tiles in layer 1, 298 in layer 2
-    (8, {"plan_cus": 64}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),       # planned for a 64-CU chip: both big tiles, one workgroup per tile
-    (8, {"plan_cus": 64, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),   # persistent grid + phase stagger (A/B forms)
-    (8, {"plan_cus": 64, "chain": 3}, {"bneck_chain_f16<64,128"}),                     # the 128-pixel form of the 64-plane tile
+    (8, {"plan_cus": 64, "chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64"}),   # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
+    (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),       # planned for a 32-CU chip: both big tiles, one workgroup per tile (the default form)
+    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),   # persistent grid + phase stagger (A/B forms)
+    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}),                     # the 128-pixel form of the 64-plane tile
 ])
 def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want):
     import yolact_amd as ya

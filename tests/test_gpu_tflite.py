@@ -215,3 +215,36 @@ def test_conv_random_geometries_bit_exact(built):
         eng, val, outs = _run_both(model, x)
         assert np.array_equal(outs[0], val[model.outputs[0]]), (code, kw)
         eng.close()
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_batch_plan_two_tiles_in_one_invoke_equals_two_invokes(built, graph):
+    """yh_tfl_set_batch(2): the reference invokes its batch-1 model once per tile (yolact.rs:216-217); the two tiles are
+    independent, so they run as ONE pass of the plan with image-major activations. Every written tensor of the full-size
+    stand-in for both images == the numpy oracle on each image alone, bit for bit; then back to one image per invoke."""
+    import yolact_amd as ya
+    rng = np.random.default_rng(23)
+    model = M.mobilenetv2_yolact(rng)
+    x2 = rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8)
+    eng = ya.TfliteEngine(B.serialize(model), tune=dict(tfl_graph=graph))
+    eng.set_batch(2)
+    eng.set_input(x2)
+    eng.invoke()
+    import tfl_oracle as TO
+    vals = [TO.run_model(model, {model.inputs[0]: x2[i:i + 1]}) for i in range(2)]
+    written = sorted({o for op in model.ops for o in op.outputs})
+    for i in written[::5] + list(model.outputs):
+        t = model.tensors[i]
+        got = eng.tensor(i, t.shape, B.NP_TYPE[t.dtype])
+        for k in range(2):
+            assert np.array_equal(got[k], np.asarray(vals[k][i]).reshape(got[k].shape)), (i, t.name, k)
+    for rep in range(3):                                  # replay: the same bits
+        eng.invoke()
+        assert np.array_equal(eng.output(4)[1], np.asarray(vals[1][model.outputs[4]]).reshape(eng.output(4)[1].shape))
+    eng.set_batch(1)
+    eng.set_input(x2[1:2])
+    eng.invoke()
+    assert np.array_equal(eng.output(4), vals[1][model.outputs[4]])
+    with pytest.raises(ya.YhError):
+        eng.set_batch(3)
+    eng.close()

@@ -48,11 +48,14 @@ struct ConvQ {
     int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, dm;
     int zx, zw, zo, mult, shift, lo, hi;
     const int* wsum;   // [Co][kh*kw]: sum of the raw weight bytes of one tap (dot-product kernel), or nullptr
+    // batch plan (yh_tfl_set_batch): the grid's last used dimension is the image; activations are image-major
+    long long xs, ys;  // bytes per image of x / y
 };
 
-__global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
+__global__ __launch_bounds__(256) void tfl_conv_u8(ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
+    p.x += blockIdx.y * p.xs; p.y += blockIdx.y * p.ys;
     const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo;
     int acc = 0;
     for (int r = 0; r < p.kh; ++r) {
@@ -80,8 +83,9 @@ __global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
 // channels (the model's layers are small: 28 x 28 pixels x 128 channels is 13 x 16 workgroups, and
 // the serial chain per lane is what takes the time) and wave 0 adds the partial sums from LDS.
 template <int KS>
-__global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(const ConvQ p) {
+__global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(ConvQ p) {
     __shared__ unsigned part[KS > 1 ? (KS - 1) * 9 * 64 : 1];
+    p.x += blockIdx.z * p.xs; p.y += blockIdx.z * p.ys;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int pix = blockIdx.x * 64 + lane, oc0 = blockIdx.y * 8;
     const bool live = pix < p.Ho * p.Wo;
@@ -139,9 +143,10 @@ __global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(const ConvQ p) {
     }
 }
 
-__global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
+__global__ __launch_bounds__(256) void tfl_dwconv_u8(ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
+    p.x += blockIdx.y * p.xs; p.y += blockIdx.y * p.ys;
     const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo, ic = oc / p.dm;
     int acc = 0;
     for (int r = 0; r < p.kh; ++r) {
@@ -208,9 +213,10 @@ __global__ __launch_bounds__(256) void tfl_pad_u8(const PadQ p) {
     p.y[t] = in ? p.x[(((long long)c[0] * p.id[1] + c[1]) * p.id[2] + c[2]) * p.id[3] + c[3]] : (uint8_t)p.fill;
 }
 struct ResizeQ { const uint8_t* x; uint8_t* y; int H, W, C, Ho, Wo; float hs, ws; int half_pixel; };
-__global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(const ResizeQ p) {
+__global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(ResizeQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.C) return;
+    p.x += (size_t)blockIdx.y * p.H * p.W * p.C; p.y += (size_t)blockIdx.y * p.Ho * p.Wo * p.C;   // (batch plan: image-major)
     const int c = t % p.C, r0 = t / p.C, ox = r0 % p.Wo, oy = r0 / p.Wo;
     const float iy = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)oy, 0.5f), p.hs), 0.5f) : __fmul_rn((float)oy, p.hs);
     const float ix = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)ox, 0.5f), p.ws), 0.5f) : __fmul_rn((float)ox, p.ws);
@@ -289,7 +295,10 @@ struct yh_tfl {
     std::vector<char> alias;    // tens[i] shares another tensor's buffer (RESHAPE): not freed twice
     std::vector<void*> extra;   // LUTs etc.
     std::vector<Prepared> plan;
-    hipGraphExec_t gexec = nullptr;   // the plan, captured once and replayed (tensor addresses never change)
+    static constexpr int kMaxBatch = 2;          // images per invoke the buffers are sized for (the two tiles of yolact.rs:216-217)
+    int nb = 1;                                  // images of the next invoke (yh_tfl_set_batch)
+    bool batch_ok = true;                        // no operator of the model touches the image axis
+    hipGraphExec_t gexecs[kMaxBatch] = { nullptr, nullptr };   // the plan per batch size, captured once and replayed (tensor addresses never change)
     int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -317,9 +326,10 @@ int prepare(yh_tfl* h) {
         const TflTensor& t = m.tensors[i];
         const size_t bytes = t.count() * t.elem();
         if (bytes == 0) continue;
-        TCHK(h, hipMalloc(&h->tens[i], bytes + 16));
+        const size_t alloc = t.data ? bytes : bytes * yh_tfl::kMaxBatch;   // activations: image-major, room for the batch plan
+        TCHK(h, hipMalloc(&h->tens[i], alloc + 16));
         if (t.data) TCHK(h, hipMemcpy(h->tens[i], t.data, bytes, hipMemcpyHostToDevice));
-        else TCHK(h, hipMemset(h->tens[i], 0, bytes));
+        else TCHK(h, hipMemset(h->tens[i], 0, alloc));
     }
     auto T = [&](int i) -> const TflTensor& { return m.tensors[i]; };
     auto need = [&](bool c, const std::string& what) { if (!c && h->err.empty()) h->err = what; return c; };
@@ -351,6 +361,7 @@ int prepare(yh_tfl* h) {
                 c.x = (const uint8_t*)h->tens[op.in[0]]; c.w = (const uint8_t*)h->tens[op.in[1]];
                 c.bias = bi >= 0 ? (const int*)h->tens[bi] : nullptr; c.y = (uint8_t*)h->tens[op.out[0]];
                 c.zx = x.zp; c.zw = w.zp; c.zo = y.zp;
+                c.xs = (long long)c.H * c.W * c.Ci; c.ys = (long long)c.Ho * c.Wo * c.Co;
                 quantize_multiplier((double)x.scale * (double)w.scale / (double)y.scale, &c.mult, &c.shift);
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
@@ -437,6 +448,7 @@ int prepare(yh_tfl* h) {
                     q.id[d] = x.shape[d]; q.before[d] = pp[2 * d]; q.od[d] = x.shape[d] + pp[2 * d] + pp[2 * d + 1];
                     if (!need(pp[2 * d] >= 0 && pp[2 * d + 1] >= 0 && y.shape[d] == q.od[d], "pad: output shape mismatch" + at)) return YH_EINVAL;
                 }
+                if (q.id[0] != 1 || q.od[0] != 1) h->batch_ok = false;
                 q.x = (const uint8_t*)h->tens[op.in[0]]; q.y = (uint8_t*)h->tens[op.out[0]]; q.fill = y.zp;
                 pr.kind = P_PAD;
                 break;
@@ -460,6 +472,7 @@ int prepare(yh_tfl* h) {
                 const int nd = (int)y.shape.size();
                 const int axis = op.axis < 0 ? op.axis + nd : op.axis;
                 if (!need(axis >= 0 && axis < nd && !op.in.empty(), "concatenation: bad axis" + at)) return YH_EINVAL;
+                if (axis == 0) h->batch_ok = false;   // (joins along the image axis: this model runs one image per invoke only)
                 long long outer = 1; int inner_o = 1;
                 for (int d = 0; d < axis; ++d) outer *= y.shape[d];
                 for (int d = axis; d < nd; ++d) inner_o *= y.shape[d];
@@ -510,26 +523,31 @@ int prepare(yh_tfl* h) {
 
 int enqueue_plan(yh_tfl* h) {
     hipStream_t s = h->stream;
-    for (const Prepared& p : h->plan) {
+    const unsigned nb = (unsigned)h->nb;   // images of this invoke: activations are image-major, so element-wise ops just see nb x the elements
+    TraceRange tr_all("yh_tfl:plan(enqueue)");
+    for (size_t pi = 0; pi < h->plan.size(); ++pi) {
+        const Prepared& p = h->plan[pi];
+        static const char* kind_name[] = { "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RELU/QUANTIZE", "QUANTIZE(f32)", "DEQUANTIZE", "TANH", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE(copy)" };
+        TraceRange tr(kind_name[p.kind]);   // (roctx: one range per operator, named by its TFLite op; a no-op unless a tracer is attached)
         switch (p.kind) {
             case P_CONV:
                 if (p.conv.wsum) {
-                    const dim3 grid((unsigned)(((long long)p.conv.Ho * p.conv.Wo + 63) / 64), (unsigned)((p.conv.Co + 7) / 8));
+                    const dim3 grid((unsigned)(((long long)p.conv.Ho * p.conv.Wo + 63) / 64), (unsigned)((p.conv.Co + 7) / 8), nb);
                     if (p.conv.Ci % 16 == 0) hipLaunchKernelGGL(tfl_conv_u8_dot<4>, grid, dim3(256), 0, s, p.conv);
                     else hipLaunchKernelGGL(tfl_conv_u8_dot<1>, grid, dim3(64), 0, s, p.conv);
                 }
-                else hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv);
+                else hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv);
                 break;
-            case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co)), dim3(256), 0, s, p.conv); break;
-            case P_ADD: hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(p.add.n)), dim3(256), 0, s, p.add); break;
-            case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
-            case P_QUANT_F32: hipLaunchKernelGGL(tfl_quantize_f32, dim3(nblk(p.n)), dim3(256), 0, s, (const float*)p.src, (uint8_t*)p.dst, p.n, p.scale, p.zo); break;
-            case P_DEQUANT: hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (float*)p.dst, p.n, p.scale, p.zi); break;
-            case P_LUT: hipLaunchKernelGGL(tfl_lut_u8, dim3(nblk(p.n)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n, p.lut); break;
-            case P_PAD: hipLaunchKernelGGL(tfl_pad_u8, dim3(nblk((long long)p.pad.od[0] * p.pad.od[1] * p.pad.od[2] * p.pad.od[3])), dim3(256), 0, s, p.pad); break;
-            case P_RESIZE: hipLaunchKernelGGL(tfl_resize_bilinear_u8, dim3(nblk((long long)p.rs.Ho * p.rs.Wo * p.rs.C)), dim3(256), 0, s, p.rs); break;
-            case P_CONCAT: for (const CatQ& c : p.cat) hipLaunchKernelGGL(tfl_concat_part, dim3(nblk(c.outer * c.inner * c.esz)), dim3(256), 0, s, c); break;
-            case P_COPY: hipLaunchKernelGGL(tfl_copy_bytes, dim3(nblk((p.n >> 4) + 16)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n); break;
+            case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv); break;
+            case P_ADD: { AddQ q = p.add; q.n *= nb; hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(q.n)), dim3(256), 0, s, q); break; }
+            case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
+            case P_QUANT_F32: hipLaunchKernelGGL(tfl_quantize_f32, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const float*)p.src, (uint8_t*)p.dst, p.n * nb, p.scale, p.zo); break;
+            case P_DEQUANT: hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const uint8_t*)p.src, (float*)p.dst, p.n * nb, p.scale, p.zi); break;
+            case P_LUT: hipLaunchKernelGGL(tfl_lut_u8, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb, p.lut); break;
+            case P_PAD: { PadQ q = p.pad; q.id[0] *= (int)nb; q.od[0] *= (int)nb; hipLaunchKernelGGL(tfl_pad_u8, dim3(nblk((long long)q.od[0] * q.od[1] * q.od[2] * q.od[3])), dim3(256), 0, s, q); break; }
+            case P_RESIZE: hipLaunchKernelGGL(tfl_resize_bilinear_u8, dim3(nblk((long long)p.rs.Ho * p.rs.Wo * p.rs.C), nb), dim3(256), 0, s, p.rs); break;
+            case P_CONCAT: for (CatQ c : p.cat) { c.outer *= nb; hipLaunchKernelGGL(tfl_concat_part, dim3(nblk(c.outer * c.inner * c.esz)), dim3(256), 0, s, c); } break;
+            case P_COPY: hipLaunchKernelGGL(tfl_copy_bytes, dim3(nblk(((p.n * nb) >> 4) + 16)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb); break;
         }
     }
     hipError_t e = hipGetLastError();
@@ -549,7 +567,8 @@ int enqueue_plan(yh_tfl* h) {
 // memory access fault WITHOUT the profiler (engine.hip, enqueue_all), so this library never builds a single-branch graph.
 int run_plan(yh_tfl* h) {
     if (!h->use_graph) return enqueue_plan(h);
-    if (!h->gexec) {
+    hipGraphExec_t& gexec = h->gexecs[h->nb - 1];
+    if (!gexec) {
         hipGraph_t g = nullptr;
         TCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
         // Inside the capture window nothing returns early: a failure is collected, the side stream is joined and the capture
@@ -572,11 +591,11 @@ int run_plan(yh_tfl* h) {
             return h->fail(YH_EHIP, ce != hipSuccess ? std::string("tflite plan capture (") + where + "): " + hipGetErrorString(ce)
                                                      : std::string("tflite plan capture: ") + hipGetErrorString(e));
         }
-        const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        const hipError_t ei = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
-        if (ei != hipSuccess) { h->gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
+        if (ei != hipSuccess) { gexec = nullptr; return h->fail(YH_EHIP, std::string("tflite plan instantiate: ") + hipGetErrorString(ei)); }
     }
-    TCHK(h, hipGraphLaunch(h->gexec, h->stream));
+    TCHK(h, hipGraphLaunch(gexec, h->stream));
     return YH_OK;
 }
 
@@ -634,7 +653,7 @@ void yh_tfl_destroy(yh_tfl* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    for (hipGraphExec_t ge : h->gexecs) if (ge) hipGraphExecDestroy(ge);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -660,10 +679,18 @@ int yh_tfl_output_info(const yh_tfl* h, int32_t i, yh_tensor_info* info) {
 }
 int yh_tfl_tensor_count(const yh_tfl* h) { return h ? (int)h->m.tensors.size() : YH_EINVAL; }
 
+int yh_tfl_set_batch(yh_tfl* h, int32_t n_images) {
+    if (!h) return YH_EINVAL;
+    if (n_images < 1 || n_images > yh_tfl::kMaxBatch) return h->fail(YH_EINVAL, "1 or 2 images per invoke");
+    if (n_images > 1 && !h->batch_ok) return h->fail(YH_EINVAL, "an operator of this model works along the image axis: one image per invoke only");
+    h->nb = n_images;
+    return YH_OK;
+}
+
 int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes) {
     if (!h || !data) return YH_EINVAL;
     const TflTensor& t = h->m.tensors[h->m.inputs[0]];
-    if (nbytes != t.count() * t.elem()) return h->fail(YH_EINVAL, "input size mismatch");   // the reference only warns (yolact.rs:151-158)
+    if (nbytes != t.count() * t.elem() * (size_t)h->nb) return h->fail(YH_EINVAL, "input size mismatch");   // the reference only warns (yolact.rs:151-158)
     TCHK(h, hipSetDevice(h->dev));
     TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], data, nbytes, hipMemcpyHostToDevice, h->stream));
     // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. From pageable memory the
@@ -676,12 +703,13 @@ int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes) {
 int yh_tfl_invoke(yh_tfl* h) {
     if (!h) return YH_EINVAL;
     TCHK(h, hipSetDevice(h->dev));
+    TraceRange tr("yh_tfl_invoke");
     return run_plan(h);
 }
 int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes) {
     if (!h || !dst || tensor < 0 || tensor >= (int)h->m.tensors.size()) return YH_EINVAL;
     const TflTensor& t = h->m.tensors[tensor];
-    if (nbytes != t.count() * t.elem()) return h->fail(YH_EINVAL, "tensor size mismatch");
+    if (nbytes != t.count() * t.elem() * (size_t)(t.data ? 1 : h->nb)) return h->fail(YH_EINVAL, "tensor size mismatch (activations hold yh_tfl_set_batch images)");
     TCHK(h, hipSetDevice(h->dev));
     TCHK(h, hipMemcpyAsync(dst, h->tens[tensor], nbytes, hipMemcpyDeviceToHost, h->stream));
     TCHK(h, hipStreamSynchronize(h->stream));
@@ -716,18 +744,36 @@ int yh_tfl_classify_frame_u32(yh_tfl* h, uint32_t* frame, int32_t w, int32_t hh,
             hipMalloc((void**)&h->diverged_dev, 8) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc scratch");
     }
     hipStream_t s = h->stream;
+    TraceRange tr("yh_tfl_classify_frame_u32");
     // yolact.rs:195-214
     TCHK(h, hipMemcpyAsync(h->frame_dev, frame, npx * 4, hipMemcpyHostToDevice, s));
     hipError_t e = launch_resize_v_u32(h->frame_dev, w, hh, h->rs_tmp, S, s);
-    if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->tiles_dev, 2 * S, 1, s);
-    if (e != hipSuccess) return h->fail(YH_EHIP, "classify pre failed");
-    for (int t = 0; t < 2; ++t) {   // yolact.rs:216-217: the two tiles, one invoke each (the model is batch 1)
-        TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], h->tiles_dev + (size_t)t * S * S * 3, (size_t)S * S * 3, hipMemcpyDeviceToDevice, s));
-        int rc = run_plan(h);
+    const int nb_saved = h->nb;
+    if (h->batch_ok) {
+        // yolact.rs:216-217: the two tiles are independent - they run as ONE invoke of the batch plan (the horizontal resize
+        // writes them, image-major, straight into the input tensor): half the launches per frame, twice the work per launch
+        if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->tens[h->m.inputs[0]], 2 * S, 1, s);
+        if (e != hipSuccess) return h->fail(YH_EHIP, "classify pre failed");
+        h->nb = 2;
+        const int rc = run_plan(h);
+        h->nb = nb_saved;
         if (rc) return rc;
-        float* dst = h->cells_dev + (size_t)t * cells * C;   // yolact.rs:169-182: outputs -> f32 (results[4])
-        if (o4.type == TFL_U8) hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk((long long)cells * C)), dim3(256), 0, s, (const uint8_t*)h->tens[h->m.outputs[4]], dst, (long long)(cells * C), o4.scale, o4.zp);
-        else TCHK(h, hipMemcpyAsync(dst, h->tens[h->m.outputs[4]], cells * C * 4, hipMemcpyDeviceToDevice, s));
+        // yolact.rs:169-182: outputs -> f32 (results[4]), both tiles
+        if (o4.type == TFL_U8) hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk((long long)2 * cells * C)), dim3(256), 0, s, (const uint8_t*)h->tens[h->m.outputs[4]], h->cells_dev, (long long)(2 * cells * C), o4.scale, o4.zp);
+        else TCHK(h, hipMemcpyAsync(h->cells_dev, h->tens[h->m.outputs[4]], 2 * cells * C * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        if (e == hipSuccess) e = launch_resize_h(h->rs_tmp, w, S, h->tiles_dev, 2 * S, 1, s);
+        if (e != hipSuccess) return h->fail(YH_EHIP, "classify pre failed");
+        h->nb = 1;
+        for (int t = 0; t < 2; ++t) {   // one invoke per tile (an operator of this model works along the image axis)
+            TCHK(h, hipMemcpyAsync(h->tens[h->m.inputs[0]], h->tiles_dev + (size_t)t * S * S * 3, (size_t)S * S * 3, hipMemcpyDeviceToDevice, s));
+            const int rc = run_plan(h);
+            if (rc) { h->nb = nb_saved; return rc; }
+            float* dst = h->cells_dev + (size_t)t * cells * C;
+            if (o4.type == TFL_U8) hipLaunchKernelGGL(tfl_dequantize_u8, dim3(nblk((long long)cells * C)), dim3(256), 0, s, (const uint8_t*)h->tens[h->m.outputs[4]], dst, (long long)(cells * C), o4.scale, o4.zp);
+            else TCHK(h, hipMemcpyAsync(dst, h->tens[h->m.outputs[4]], cells * C * 4, hipMemcpyDeviceToDevice, s));
+        }
+        h->nb = nb_saved;
     }
     e = launch_cells_postprocess(h->cells_dev, 2, grid, C, mode, h->codes_dev, h->diverged_dev, s);   // yolact.rs:90-131
     if (e == hipSuccess) e = launch_upsample_codes(h->codes_dev, 2, grid, h->stitch_dev, 1, s);        // :127-128, :219-220

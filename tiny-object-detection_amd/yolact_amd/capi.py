@@ -127,6 +127,7 @@ SYMBOLS = [
     ("yh_tfl_input_info", _i, [_vp, C.POINTER(TensorInfo)]),
     ("yh_tfl_output_count", _i, [_vp]),
     ("yh_tfl_output_info", _i, [_vp, _i, C.POINTER(TensorInfo)]),
+    ("yh_tfl_set_batch", _i, [_vp, _i]),
     ("yh_tfl_set_input", _i, [_vp, _vp, _sz]),
     ("yh_tfl_invoke", _i, [_vp]),
     ("yh_tfl_output_read", _i, [_vp, _i, _vp, _sz]),
@@ -746,6 +747,11 @@ class TfliteEngine:
         self._chk(self.L.yh_tfl_output_info(self.h, i, C.byref(ti)))
         return self._info(ti)
 
+    def set_batch(self, n):
+        """1 or 2 images per invoke (the two tiles of a frame as one pass); inputs / outputs / tensors then carry n images."""
+        self._chk(self.L.yh_tfl_set_batch(self.h, n))
+        self.nb = n
+
     def set_input(self, arr):
         arr = np.ascontiguousarray(arr)
         self._chk(self.L.yh_tfl_set_input(self.h, _p(arr), arr.nbytes))
@@ -755,12 +761,14 @@ class TfliteEngine:
 
     def output(self, i):
         info = self.output_info(i)
-        out = np.empty(info["dims"], _KIND_NP[info["kind"]])
+        nb = getattr(self, "nb", 1)
+        out = np.empty(((nb,) + tuple(info["dims"])) if nb > 1 else info["dims"], _KIND_NP[info["kind"]])
         self._chk(self.L.yh_tfl_output_read(self.h, i, _p(out), out.nbytes))
         return out
 
     def tensor(self, index, shape, dtype):
-        out = np.empty(shape, dtype)
+        nb = getattr(self, "nb", 1)
+        out = np.empty(((nb,) + tuple(shape)) if nb > 1 else shape, dtype)
         self._chk(self.L.yh_tfl_tensor_read(self.h, index, _p(out), out.nbytes))
         return out
 
