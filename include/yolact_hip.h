@@ -90,7 +90,8 @@ typedef struct yh_tuning {
                               * descriptors: the loads issue, nothing moves), bit 2 issues no loader instruction at all */
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
-    int32_t tfl_dot;         /* TFLite path: dot-product conv kernel (1) */
+    int32_t tfl_dot;         /* TFLite path, CONV_2D: 0 one lane per output element, 1 the v_dot4 kernel (Ci % 4 == 0), 2 (default) also the
+                              * int8 MFMA kernel where Ci % 64 == 0; all three give the same bytes */
     int32_t tfl_graph;       /* TFLite path: 0 eager launches (default, and the faster form: 1.10 vs 1.22 ms), 1 hipGraph replay
                               * of the plan (captured with a second, one-node branch: DESIGN.md §8 on single-branch graphs) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0 keeps them on

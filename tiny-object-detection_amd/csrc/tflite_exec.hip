@@ -143,6 +143,121 @@ __global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(ConvQ p) {
     }
 }
 
+// ---- CONV_2D on the int8 matrix pipes: Ci % 64 == 0 (the FPN / protonet / head 3x3 convolutions of the
+// model family - 85 % of its MACs - and the wide 1x1 convolutions). uint8 operands become int8 by flipping the top bit
+// (x' = x - 128, w' = w - 128), v_mfma_i32_16x16x64_i8 accumulates sum(x' w') exactly in int32, and
+//   sum (x - zx)(w - zw) = sum x'w' + (128 - zw) sum x' + (128 - zx) sum w' + K (128 - zx)(128 - zw)
+// restores TFLite's value bit for bit: sum w' per channel is tabulated at load time, sum x' per output pixel is a v_dot4 beside
+// the MFMAs, and a padded tap is fed the input's zero point (x - zx = 0: TFLite skips it). Implicit GEMM: a workgroup owns
+// 64 channels x 64 output pixels (images of the batch plan are folded into the pixel index), four waves of 32 x 32, one tap's
+// 64 channels per k-step, register-staged double buffer (tiles are 4 KB: the layers are small and latency-bound).
+struct ConvI8 {
+    const uint8_t* x; const uint8_t* wq; const int* cterm; uint8_t* y;   // wq: [CoPad][K] bytes w ^ 0x80, K = (r, s, c); cterm: [CoPad]
+    int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw;
+    int zx, zw, zo, mult, shift, lo, hi, K, M;
+    long long xs, ys;
+};
+typedef int v4i __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
+    __shared__ __attribute__((aligned(16))) char lds[2][8192];   // [stage][A 64 rows x 64 B | B 64 rows x 64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.x * 64, ch0 = blockIdx.y * 64;
+    // loader role: 16-byte chunk `lchunk` of row `lrow` of both tiles
+    const int lrow = tid >> 2, lchunk = tid & 3;
+    const int HoWo = p.Ho * p.Wo;
+    const int m = m0 + lrow;
+    const bool mlive = m < p.M;
+    const int img = mlive ? m / HoWo : 0, rem = mlive ? m - img * HoWo : 0, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const uint8_t* ximg = p.x + (long long)img * p.xs;
+    const uint8_t* wrow = p.wq + (size_t)(ch0 + lrow) * p.K + lchunk * 16;
+    const unsigned zx4 = (unsigned)p.zx * 0x01010101u;
+    const int lds_w = lrow * 64 + ((lchunk ^ ((lrow >> 2) & 3)) << 4);
+    const int cchunks = p.Ci >> 6, nsteps = p.kh * p.kw * cchunks;
+    uint4 ra, rb;
+    auto fetch = [&](int step) {
+        const int tap = step / cchunks, cc = step - tap * cchunks, r = tap / p.kw, s_ = tap - r * p.kw;
+        ra = *(const uint4*)(wrow + (size_t)step * 64);        // K index = tap * Ci + cc * 64 = step * 64
+        const int iy = oy * p.sh - p.ph + r * p.dh, ix = ox * p.sw - p.pw + s_ * p.dw;
+        if (mlive && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            rb = *(const uint4*)(ximg + ((size_t)iy * p.W + ix) * p.Ci + cc * 64 + lchunk * 16);
+        else rb = make_uint4(zx4, zx4, zx4, zx4);              // padded tap (and rows past M): x = zx contributes (x - zx) = 0
+    };
+    auto stash = [&](int st) {
+        *(uint4*)(lds[st] + lds_w) = ra;
+        *(uint4*)(lds[st] + 4096 + lds_w) = rb;
+    };
+    const int wc = wave >> 1, wm = wave & 1;
+    v4i acc[2][2];
+    unsigned sx[2] = { 0u, 0u };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = v4i{ 0, 0, 0, 0 };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int st = step & 1;
+        if (step + 1 < nsteps) fetch(step + 1);                // in flight under this step's MFMAs
+        v4i fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wc * 32 + i * 16 + l15;
+            fa[i] = *(const v4i*)(lds[st] + row * 64 + ((lg ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wm * 32 + j * 16 + l15;
+            const v4i raw = *(const v4i*)(lds[st] + 4096 + row * 64 + ((lg ^ ((row >> 2) & 3)) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sx[j] = __builtin_amdgcn_udot4((unsigned)raw[e], 0x01010101u, sx[j], false);
+                fb[j][e] = raw[e] ^ (int)0x80808080u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (step + 1 < nsteps) {
+            stash(st ^ 1);                                     // (the other stage was last read one step ago, behind a barrier)
+            __syncthreads();
+        }
+    }
+    // sum x over the whole K of this lane's pixel: the four lane groups hold the four 16-byte quarters of every k-step
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sx[j] += __shfl_xor(sx[j], 16);
+        sx[j] += __shfl_xor(sx[j], 32);
+    }
+    // lane: pixel (wm, j, l15), channels (wc, i, 4 lg + e)   [C/D layout of the 16 x 16 MFMA: column = lane & 15, rows 4 (lane >> 4) + e]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mo = m0 + wm * 32 + j * 16 + l15;
+        if (mo >= p.M) continue;
+        const int im = mo / HoWo, px = mo - im * HoWo;
+        uint8_t* yrow = p.y + (long long)im * p.ys + (size_t)px * p.Co;
+        const int xterm = (128 - p.zw) * ((int)sx[j] - 128 * p.K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = ch0 + wc * 32 + i * 16 + 4 * lg;
+            if (ch >= p.Co) continue;
+            unsigned packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = acc[i][j][e] + xterm + p.cterm[ch + e];   // (cterm is padded to CoPad)
+                const unsigned q = (unsigned)q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi);
+                packed |= q << (8 * e);
+            }
+            if ((p.Co & 3) == 0) *(unsigned*)(yrow + ch) = packed;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ch + e < p.Co) yrow[ch + e] = (uint8_t)(packed >> (8 * e));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tfl_dwconv_u8(ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
@@ -273,10 +388,10 @@ void same_pad(int in, int k, int stride, int dil, int* out, int* before) {
     *before = total > 0 ? total / 2 : 0;
 }
 
-enum PKind { P_CONV, P_DW, P_ADD, P_REQUANT, P_QUANT_F32, P_DEQUANT, P_LUT, P_PAD, P_RESIZE, P_CONCAT, P_COPY };
+enum PKind { P_CONV, P_DW, P_ADD, P_REQUANT, P_QUANT_F32, P_DEQUANT, P_LUT, P_PAD, P_RESIZE, P_CONCAT, P_COPY, P_CONV_I8 };
 struct Prepared {
     PKind kind;
-    ConvQ conv; AddQ add; PadQ pad; ResizeQ rs;
+    ConvQ conv; ConvI8 ci8; AddQ add; PadQ pad; ResizeQ rs;
     std::vector<CatQ> cat;
     const void* src = nullptr; void* dst = nullptr; long long n = 0;
     int zi = 0, zo = 0, m = 0, s = 0, lo = 0, hi = 255; float scale = 1.0f;
@@ -299,7 +414,7 @@ struct yh_tfl {
     int nb = 1;                                  // images of the next invoke (yh_tfl_set_batch)
     bool batch_ok = true;                        // no operator of the model touches the image axis
     hipGraphExec_t gexecs[kMaxBatch] = { nullptr, nullptr };   // the plan per batch size, captured once and replayed (tensor addresses never change)
-    int use_dot = 1, use_graph = 0;   // yh_tuning.tfl_dot / tfl_graph
+    int use_dot = 2, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel where Ci % 64 == 0: default) / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* side_word = nullptr;
@@ -366,6 +481,31 @@ int prepare(yh_tfl* h) {
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
                 c.wsum = nullptr;
+                if (!dw && h->use_dot >= 2 && c.Ci % 64 == 0 && w.data && (long long)c.kh * c.kw * c.Ci < 131072) {
+                    // int8 MFMA form: the weight panel as int8 (w ^ 0x80) padded to 64-channel tiles, and per channel
+                    //   cterm = (128 - zx) sum(w - 128) + K (128 - zx)(128 - zw) + bias   (all exact in int32: |.| < 2^31 for K < 2^17)
+                    const int K = c.kh * c.kw * c.Ci, CoPad = (c.Co + 63) / 64 * 64;
+                    std::vector<uint8_t> wq((size_t)CoPad * K, 0x80);   // padding rows: w' = 0
+                    std::vector<int> ct(CoPad, 0);
+                    const int* bias_h = bi >= 0 ? (const int*)T(bi).data : nullptr;
+                    for (int o = 0; o < c.Co; ++o) {
+                        long long sw = 0;
+                        for (int k = 0; k < K; ++k) { const uint8_t b = w.data[(size_t)o * K + k]; wq[(size_t)o * K + k] = (uint8_t)(b ^ 0x80); sw += (int)b - 128; }
+                        ct[o] = (int)((128 - c.zx) * sw + (long long)K * (128 - c.zx) * (128 - c.zw) + (bias_h ? bias_h[o] : 0));
+                    }
+                    void *dwq = nullptr, *dct = nullptr;
+                    if (hipMalloc(&dwq, wq.size()) != hipSuccess || hipMalloc(&dct, ct.size() * 4) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc int8 panel");
+                    h->extra.push_back(dwq); h->extra.push_back(dct);
+                    if (hipMemcpy(dwq, wq.data(), wq.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dct, ct.data(), ct.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                        return h->fail(YH_EHIP, "int8 panel upload");
+                    ConvI8& q = pr.ci8;
+                    q.x = c.x; q.wq = (const uint8_t*)dwq; q.cterm = (const int*)dct; q.y = c.y;
+                    q.H = c.H; q.W = c.W; q.Ci = c.Ci; q.Ho = c.Ho; q.Wo = c.Wo; q.Co = c.Co; q.kh = c.kh; q.kw = c.kw; q.sh = c.sh; q.sw = c.sw;
+                    q.ph = c.ph; q.pw = c.pw; q.dh = c.dh; q.dw = c.dw; q.zx = c.zx; q.zw = c.zw; q.zo = c.zo; q.mult = c.mult; q.shift = c.shift;
+                    q.lo = c.lo; q.hi = c.hi; q.K = K; q.M = c.Ho * c.Wo; q.xs = c.xs; q.ys = c.ys;
+                    pr.kind = P_CONV_I8;
+                    break;
+                }
                 if (!dw && h->use_dot && c.Ci % 4 == 0 && w.data && (long long)c.kh * c.kw * c.Ci * 65025ll < (1ll << 31)) {
                     // per (channel, tap) sums of the raw weight bytes for the dot-product kernel
                     const int ntaps = c.kh * c.kw;
@@ -527,7 +667,7 @@ int enqueue_plan(yh_tfl* h) {
     TraceRange tr_all("yh_tfl:plan(enqueue)");
     for (size_t pi = 0; pi < h->plan.size(); ++pi) {
         const Prepared& p = h->plan[pi];
-        static const char* kind_name[] = { "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RELU/QUANTIZE", "QUANTIZE(f32)", "DEQUANTIZE", "TANH", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE(copy)" };
+        static const char* kind_name[] = { "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RELU/QUANTIZE", "QUANTIZE(f32)", "DEQUANTIZE", "TANH", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE(copy)", "CONV_2D(int8 MFMA)" };
         TraceRange tr(kind_name[p.kind]);   // (roctx: one range per operator, named by its TFLite op; a no-op unless a tracer is attached)
         switch (p.kind) {
             case P_CONV:
@@ -538,6 +678,12 @@ int enqueue_plan(yh_tfl* h) {
                 }
                 else hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv);
                 break;
+            case P_CONV_I8: {
+                ConvI8 q = p.ci8;
+                q.M = q.Ho * q.Wo * (int)nb;
+                hipLaunchKernelGGL(tfl_conv_i8_mfma, dim3((unsigned)((q.M + 63) / 64), (unsigned)((q.Co + 63) / 64)), dim3(256), 0, s, q);
+                break;
+            }
             case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv); break;
             case P_ADD: { AddQ q = p.add; q.n *= nb; hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(q.n)), dim3(256), 0, s, q); break; }
             case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
