@@ -202,11 +202,12 @@ def latency_stats(eng, n=200):
                 min_ms=round(float(t.min()), 4))
 
 
-def pcie_inclusive(eng, host_frames, steps=5):
-    """Wall-clock frames/s when the boundary is handed HOST buffers (yh_set_input_u8: pageable
-    host -> device copy of the uint8 frames, then the step, then a sync). Never the headline value."""
+def pcie_inclusive(eng, host_frames, steps=20):
+    """Wall-clock frames/s when the boundary is handed HOST buffers: yh_set_input_u8 (host -> device copy of the uint8 frames
+    into the input buffer the running step does not read, on the engine's copy stream) + yh_evaluate, `steps` times back to
+    back, one sync at the end - the copy of batch k+1 runs underneath step k. Never the headline value."""
     n = host_frames.shape[0]
-    steps = steps if n > 4 else 50
+    steps = steps if n > 4 else 100
     eng.set_input(host_frames); eng.evaluate(); eng.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -539,7 +540,12 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
         progress(f"batch {batch}: latency_stats")
         aux["latency"] = latency_stats(eng)
         progress(f"batch {batch}: pcie_inclusive")
-        aux["pcie_inclusive_fps"] = pcie_inclusive(eng, host)
+        # frames in PINNED host memory (what a capture pipeline hands over: a true DMA) and, beside it, in pageable memory
+        # (the runtime stages those through its own pinned buffers with the calling thread)
+        pinned = bufs[0].cpu().pin_memory()
+        aux["pcie_inclusive_fps"] = pcie_inclusive(eng, pinned.numpy())
+        aux["pcie_inclusive_fps_pageable"] = pcie_inclusive(eng, host)
+        del pinned
         if batch == 1:
             progress(f"batch {batch}: host_to_detections_latency")
             aux["host_to_detections_latency"] = host_to_detections_latency(eng, host)
@@ -687,7 +693,7 @@ def main():
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 {a.precision} {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
-                                   latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"],
+                                   latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"], pcie_inclusive_fps_pageable=aux1["pcie_inclusive_fps_pageable"],
                                    host_to_detections_latency=aux1.get("host_to_detections_latency"))
     if a.batch != 1 and not a.no_configs4 and not (a.backbone == 101 and a.precision == "fp8"):
         # BASELINE.json configs[4]: YOLACT-700 ResNet-101, fp8 operands on the fp8 MFMA, batch 64 across 8 GPUs = 8 frames per
@@ -705,7 +711,7 @@ def main():
                        value=round(fps4, 2), unit="frames/s", n_gpus=world, steps=s4, ms_per_step=round(dt4 / s4 * 1e3, 4), dtype="fp8",
                        net_tflops=round(fps4 * flops4 / 1e12, 2), gflop_per_frame=round(flops4 / 1e9, 2), weights_replication=how4,
                        roofline=roofline_of(prof4, a.configs4_batch), kernel_families=family_rooflines(prof4), latency=aux4["latency"],
-                       pcie_inclusive_fps=aux4["pcie_inclusive_fps"])
+                       pcie_inclusive_fps=aux4["pcie_inclusive_fps"], pcie_inclusive_fps_pageable=aux4["pcie_inclusive_fps_pageable"])
             fp8f = [k for k in rec["kernel_families"] if k["kernel"].startswith("conv_igemm_fp8")]
             if fp8f:   # the fp8 launches as one family, against the 5 PFLOP/s dense fp8 peak
                 ms = sum(k["ms"] for k in fp8f); fl = sum(k["tflops"] * k["ms"] for k in fp8f)
@@ -735,6 +741,8 @@ def main():
         "roofline": roofline_of(prof, a.batch),
         "latency": aux["latency"],
         "pcie_inclusive_fps": aux["pcie_inclusive_fps"],
+        "pcie_inclusive_fps_pageable": aux["pcie_inclusive_fps_pageable"],
+        "pcie_inclusive_note": "host frames in pinned / pageable memory through yh_set_input_u8, copy of batch k+1 under step k (two input buffers + copy stream)",
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:

@@ -110,7 +110,8 @@ typedef struct yh_tuning {
                               * on (default 1), bit 1 128-pixel tiles for 64 planes, bit 2 a persistent grid (two workgroups per CU) instead
                               * of one workgroup per tile, bit 3 (with bit 2) a phase stagger between co-resident workgroups, bit 4
                               * also fuse launches that only fill 64-pixel tiles (small batches: slower, a test hook), bits 8..
-                              * the stagger in units of 4096 clocks. Bits 1-3 are measured A/B forms, all slower than the default */
+                              * the stagger in units of 4096 clocks. Bits 1-3 are measured A/B forms, all slower than the default; bit 5
+                              * layer 1 only, bit 6 without the fused form of layer 1's FIRST block (projection shortcut) */
 } yh_tuning;
 
 typedef struct yh_config {

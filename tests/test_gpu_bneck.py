@@ -20,14 +20,18 @@ def _pair(ya, n, **tune):
     return f, u
 
 
-@pytest.mark.parametrize("n,tune,want", [
-    (1, {"chain": 17}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64"}),            # batch 1: the small tiles (test hook: bit 4)
-    (8, {"plan_cus": 64, "chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64"}),   # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
-    (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),       # planned for a 32-CU chip: both big tiles, one workgroup per tile (the default form)
-    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}),   # persistent grid + phase stagger (A/B forms)
-    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}),                     # the 128-pixel form of the 64-plane tile
+DUAL = "bneck_chain_f16<64,128,next,dual"
+
+
+@pytest.mark.parametrize("n,tune,want,chains,nexts", [
+    (1, {"chain": 17}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL}, 6, 4),            # batch 1: the small tiles (test hook: bit 4)
+    (8, {"plan_cus": 64, "chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64", DUAL}, 6, 4),   # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
+    (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128", DUAL}, 6, 4),       # planned for a 32-CU chip: both big tiles + the first-block form (the default plan of a batch-64 step)
+    (8, {"plan_cus": 32, "chain": 65}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 5, 3),   # without the first-block form (bit 6)
+    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 6, 4),   # persistent grid + phase stagger (A/B forms)
+    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}, 6, 4),                            # the 128-pixel form of the 64-plane tile
 ])
-def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want):
+def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains, nexts):
     import yolact_amd as ya
     f, u = _pair(ya, n, **tune)
     rng = np.random.default_rng(100 + n)
@@ -38,10 +42,10 @@ def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want):
         names = [p["name"] for p in f.profile(with_tail=True, reps=1)]
         got = {nm.split(":")[0].replace(",next>", "").rstrip(">") for nm in names if nm.startswith("bneck_chain")}
         assert {w for w in want} <= got, (want, got)
-        # 5 chains in R50's layers 1-2: l1b1 (+l1b2_a), l1b2, l2b1 (+l2b2_a), l2b2 (+l2b3_a), l2b3
-        assert sum(nm.startswith("bneck_chain") for nm in names) == 5 and sum(",next>" in nm for nm in names) == 3, names
-        assert len(names) == len(u.profile(with_tail=True, reps=1)) - 5 - 3 - (0 if n > 1 else 0)
-        for name in ("l1b1", "c2", "l1b2_a", "l2b1", "l2b2_a", "l2b3_a", "c3", "c4", "c5", "p3", "proto2"):
+        # the chains of R50's layers 1-2: l1b0 (first block, + l1b1_a), l1b1 (+ l1b2_a), l1b2, l2b1 (+ l2b2_a), l2b2 (+ l2b3_a), l2b3
+        assert sum(nm.startswith("bneck_chain") for nm in names) == chains and sum(",next" in nm for nm in names) == nexts, names
+        assert len(names) == len(u.profile(with_tail=True, reps=1)) - chains - nexts
+        for name in ("l1b0", "l1b1_a", "l1b1", "c2", "l1b2_a", "l2b1", "l2b2_a", "l2b3_a", "c3", "c4", "c5", "p3", "proto2"):
             for fr in (0, n - 1):
                 assert np.array_equal(f.tensor_frame(name, fr), u.tensor_frame(name, fr)), (name, fr, rep)
         for i in range(4):

@@ -55,7 +55,10 @@ __device__ __forceinline__ void bar_vm() {
 }  // namespace
 
 // WCH x WM: wave grid of the PL-channel GEMMs (conv_b, a'); W2C x W2M: of the 64-channel chunk GEMM (the expand conv).
-template <int PL, int TM, int WCH, int WM, int W2C, int W2M, bool NEXT>
+// KT2 > 0: the stage's FIRST block - no identity shortcut; the expand conv continues its K over KT2 64-channel tiles of a second
+// tensor x2 (the block input, read at stride2): y = relu([W_c | W_d] [b ; x2] + (bias_c + bias_d)), the two-source form of
+// conv_igemm_f16 (ConvParams::x2) with b coming out of LDS. The x2 tile is fetched once per tile and serves every chunk.
+template <int PL, int TM, int WCH, int WM, int W2C, int W2M, bool NEXT, int KT2 = 0>
 __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     static_assert(PL % 64 == 0 && TM % 32 == 0 && WCH * WM == 4 && W2C * W2M == 4, "four waves");
     constexpr int KT = PL / 64;                     // 64-channel k-tiles of a PL-channel tensor
@@ -65,10 +68,11 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     constexpr int XL = TM / 32, WL = PL / 32;       // LDS-DMA passes (32 rows each) of an activation / PL-row weight tile
     constexpr int NOC = (4 * PL) / 64;              // 64-channel chunks of the block output
     constexpr int P1_BYTES = (PL + TM) * 128;       // phase 1: one k-step's weight + activation tile
-    constexpr int WT2_BYTES = KT * 64 * 128, BT_BYTES = KT * TM * 128;
+    constexpr int WT2_BYTES = (KT + KT2) * 64 * 128, BT_BYTES = KT * TM * 128;
     constexpr int A_BYTES = bmax<P1_BYTES, WT2_BYTES + BT_BYTES>::v;
-    constexpr int ST_BYTES = TM * 128, WT3_BYTES = NEXT ? PL * 128 : 0;
-    constexpr int LDS_BYTES = A_BYTES + ST_BYTES + WT3_BYTES;
+    constexpr int ST_BYTES = TM * 128, WT3_BYTES = NEXT ? PL * 128 : 0, X2_BYTES = KT2 * TM * 128;
+    constexpr int LDS_BYTES = A_BYTES + ST_BYTES + WT3_BYTES + X2_BYTES;
+    constexpr int LDW3 = PL + 64 * KT2;             // row stride of the expand conv's panel ([W_c | W_d] in the two-source form)
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     lds_char* const lds3 = (lds_char*)lds;
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     char* const bt = lds + WT2_BYTES;
     char* const stage = lds + A_BYTES;
     char* const wt3 = lds + A_BYTES + ST_BYTES;
+    char* const x2t = lds + A_BYTES + ST_BYTES + WT3_BYTES;
 
     // Persistent grid: workgroup w walks tiles w, w + grid, ... The workgroups that share a CU run the same program: started
     // together they stay in lockstep (both in the MFMA / L2-bound 3x3 phase, then both in the HBM-bound expand phase) and the
@@ -102,8 +107,9 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     for (int tile = bid; tile < ntiles; tile += nwg) {
     const int m0 = tile * TM;
     // ---- residual rows of chunk oc -> registers (16 bytes per lane and pass: rows rb + 32 d, logical chunk lc)
-    half8 resv[XL];
+    half8 resv[KT2 ? 1 : XL];
     auto load_res = [&](int oc) {
+        if (KT2) return;
 #pragma unroll
         for (int d = 0; d < XL; ++d) {
             const int m = m0 + rb + 32 * d;
@@ -111,6 +117,19 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
         }
     };
     load_res(0);   // (lands under phase 1)
+    if (KT2) {   // the second source's rows of this tile -> X2t (LDS-DMA; waited for by phase 1's first barrier)
+        const __amdgpu_buffer_rsrc_t x2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, (int)p.x2_bytes, 0x00020000);
+        lds_char* const dstx = lds3 + (A_BYTES + ST_BYTES + WT3_BYTES) + wave * 1024;
+#pragma unroll
+        for (int d = 0; d < XL; ++d) {
+            const int mm = m0 + rb + 32 * d, m = mm < p.M ? mm : 0;
+            const int n = m / PQ, rem = m - n * PQ, op = rem / p.Q, oq = rem - op * p.Q;
+            const unsigned off = (unsigned)((int)(n * p.x2_img_stride) + (op * p.W2 + oq) * p.stride2 * (64 * KT2) + lc * 8) * 2u;
+#pragma unroll
+            for (int kt = 0; kt < KT2; ++kt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rsrc, dstx + kt * (TM * 128) + d * 4096, 16, (int)(off + kt * 128u), 0, 0, 0);
+        }
+    }
 
     // ---- phase 1: b = relu(conv3x3(a) + bias_b), streaming-tile loop (one LDS stage; the co-resident workgroup overlaps)
     int xbase[XL], xih[XL], xiw[XL];
@@ -171,10 +190,10 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     auto dma_wt2 = [&](int oc) {
         lds_char* const dstw = lds3 + wave * 1024;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT + KT2; ++kt)
 #pragma unroll
             for (int d = 0; d < 2; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, dstw + kt * 8192 + d * 4096, 16, (int)((unsigned)(((oc * 64 + rb + 32 * d) * PL + kt * 64 + lc * 8) * 2)), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, dstw + kt * 8192 + d * 4096, 16, (int)((unsigned)(((oc * 64 + rb + 32 * d) * LDW3 + kt * 64 + lc * 8) * 2)), 0, 0, 0);
     };
     auto dma_wt3 = [&](int oc) {
         if (!NEXT) return;
@@ -215,8 +234,10 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     const int a2_row = ((wave / W2M) * W2TC + l31) * 128, b2_row = ((wave % W2M) * W2TM + l31) * 128;
     for (int oc = 0; oc < NOC; ++oc) {
         // S0: the residual rows of this chunk -> stage (they were requested one chunk ago); a' weights of this chunk on their way
+        if (!KT2) {
 #pragma unroll
-        for (int d = 0; d < XL; ++d) *(half8*)(stage + (rb + 32 * d) * 128 + pc * 16) = resv[d];
+            for (int d = 0; d < XL; ++d) *(half8*)(stage + (rb + 32 * d) * 128 + pc * 16) = resv[d];
+        }
         dma_wt3(oc);
         bar_vm<N3>();   // S1: Wt2(oc) has landed (issued before Wt3), the residual and (chunk 0) Bt are visible
         // S2: chunk GEMM  acc2[64 ch][TM] = W_c[oc*64 .. +63][:] x b
@@ -228,15 +249,16 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT + KT2; ++kt)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int co = ((2 * kk + lh) ^ swz) << 4;
                 half8 fa[TC2], fb[TMT2];
+                const char* const bsrc = kt < KT ? bt + kt * (TM * 128) : x2t + (kt - KT) * (TM * 128);   // b, then the second source
 #pragma unroll
                 for (int i = 0; i < TC2; ++i) fa[i] = *(const half8*)(wt2 + kt * 8192 + a2_row + i * 4096 + co);
 #pragma unroll
-                for (int j = 0; j < TMT2; ++j) fb[j] = *(const half8*)(bt + kt * (TM * 128) + b2_row + j * 4096 + co);
+                for (int j = 0; j < TMT2; ++j) fb[j] = *(const half8*)(bsrc + b2_row + j * 4096 + co);
 #pragma unroll
                 for (int i = 0; i < TC2; ++i)
 #pragma unroll
@@ -255,19 +277,20 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
                 for (int j = 0; j < TMT2; ++j) {
                     const int m = (wave % W2M) * W2TM + j * 32 + l31;
                     half4* const q = (half4*)(stage + m * 128 + (((ch >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2);
-                    const half4 r4 = *q;
+                    half4 r4;
+                    if (!KT2) r4 = *q;
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc2[i][j][4 * g + e] + b4[e];
-                        v = v + (float)r4[e];
+                        if (!KT2) v = v + (float)r4[e];
                         o[e] = (half_t)fmaxf(v, 0.0f);
                     }
                     *q = o;
                 }
             }
         // S5: the y chunk is complete; Wt3(oc) has landed (only the residual loads of S3 may still be in flight)
-        if (oc + 1 < NOC) bar_vm<XL>(); else bar_vm<0>();
+        if (oc + 1 < NOC && !KT2) bar_vm<XL>(); else bar_vm<0>();
         // S6: whole-row stores of the y chunk; the next chunk's expand weights; a' += W_a'[:, chunk] x y chunk
 #pragma unroll
         for (int d = 0; d < XL; ++d) {
@@ -327,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     }   // persistent tile loop
 }
 
-const char* bneck_symbol(int planes, int tm, bool next) {
+const char* bneck_symbol(int planes, int tm, bool next, bool dual) {
+    if (dual) return "bneck_chain_f16<64,128,next,dual>";
     if (planes == 64 && tm == 128) return next ? "bneck_chain_f16<64,128,next>" : "bneck_chain_f16<64,128>";
     if (planes == 64) return tm == 256 ? (next ? "bneck_chain_f16<64,256,next>" : "bneck_chain_f16<64,256>") : (next ? "bneck_chain_f16<64,64,next>" : "bneck_chain_f16<64,64>");
     return tm == 128 ? (next ? "bneck_chain_f16<128,128,next>" : "bneck_chain_f16<128,128>") : (next ? "bneck_chain_f16<128,64,next>" : "bneck_chain_f16<128,64>");
@@ -340,6 +364,11 @@ hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t st
     const int slots = p.grid_cap > 0 ? p.grid_cap : ntiles;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     const bool next = p.a_next != nullptr;
+    if (p.x2) {   // the stage's first block (two-source expand conv): 64 planes, 64-channel second source, 128-pixel tiles
+        if (planes != 64 || tm != 128 || p.C2 != 64 || !next || p.res) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((bneck_chain_f16<64, 128, 1, 4, 1, 4, true, 1>), grid, dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     if (planes == 64 && tm == 256) {
         if (next) hipLaunchKernelGGL((bneck_chain_f16<64, 256, 1, 4, 1, 4, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((bneck_chain_f16<64, 256, 1, 4, 1, 4, false>), grid, dim3(256), 0, stream, p);

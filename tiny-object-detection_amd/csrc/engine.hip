@@ -491,7 +491,8 @@ int build_graph_spec(yh_engine* h) {
     // launch. Which launches really fuse is decided per batch size (chain_active): the links only say what may.
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockOps& bo = blocks[i];
-        if (!bo.identity || (bo.planes != 64 && bo.planes != 128)) continue;
+        // (a stage's FIRST block - projection shortcut, two-source expand conv - has a fused form for 64 planes: layer 1)
+        if ((!bo.identity && !(bo.planes == 64 && h->ops[bo.c].dual)) || (bo.planes != 64 && bo.planes != 128)) continue;
         Op& ob = h->ops[bo.b];
         ob.chain_c = bo.c;
         h->ops[bo.c].in_chain = bo.b;
@@ -1017,13 +1018,17 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
     if (!(h->tune.chain & 1) || h->cfg.debug_tensors || ob.chain_c < 0 || n < 1) return false;
     // Launches too small for two big tiles per CU stay separate: with few, long-lived workgroups the serial chain is slower than
     // three short launches (batch 1: 0.723 vs 0.711 ms per step with 64-pixel tiles). tune.chain bit 4 fuses them anyway (tests).
-    if (chain_tile_m(h, ob, n) == 64 && !(h->tune.chain & 16)) return false;
+    const int ctm = chain_tile_m(h, ob, n);
+    if (ctm == 0 || (ctm == 64 && !(h->tune.chain & 16))) return false;
     const Op& oc = h->ops[ob.chain_c];
     const int planes = h->panels[ob.panel].cout;
     if (planes == 128 && (h->tune.chain & 32)) return false;   // (A/B: chains in layer 1 only)
-    if ((planes != 64 && planes != 128) || ob.stride != 1 || ob.in.c != planes || oc.out.c != 4 * planes || !oc.has_res || oc.res_up || oc.dual || oc.res.c != 4 * planes) return false;
+    if ((planes != 64 && planes != 128) || ob.stride != 1 || ob.in.c != planes || oc.out.c != 4 * planes || oc.res_up) return false;
     const long long pq = (long long)ob.P * ob.Q;
-    if (oc.out.img_stride != pq * oc.out.c || oc.res.img_stride != pq * oc.res.c) return false;
+    if (oc.dual) {   // the stage's first block: 64 planes, 64-channel second source at stride 1, and a next block to hand a' to
+        if ((h->tune.chain & 64) || planes != 64 || oc.has_res || oc.in2.c != 64 || oc.stride2 != 1 || ob.chain_a < 0) return false;
+    } else if (!oc.has_res || oc.res.c != 4 * planes || oc.res.img_stride != pq * oc.res.c) return false;
+    if (oc.out.img_stride != pq * oc.out.c) return false;
     if (h->fp8_active && (ob.write_q || oc.write_q || !oc.write_f16)) return false;
     if (ob.chain_a >= 0) {
         const Op& oa = h->ops[ob.chain_a];
@@ -1032,6 +1037,7 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
     return true;
 }
 int chain_tile_m(const yh_engine* h, const Op& ob, int n) {
+    if (h->ops[ob.chain_c].dual) return ((long long)n * ob.P * ob.Q >= 8ll * h->tune.plan_cus * 128 || (h->tune.chain & 16)) ? 128 : 0;   // (one tile size; 0: inactive)
     const int planes = h->panels[ob.panel].cout, big = planes == 64 ? ((h->tune.chain & 2) ? 128 : 256) : 128;   // (tune.chain bit 1: A/B of the 64-plane tile)
     const long long M = (long long)n * ob.P * ob.Q;
     // The big tiles from about four rounds of two workgroups per CU on: measured, the chain gains 1.6 % of a batch-64 step (9.3
@@ -1049,8 +1055,13 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
     p.N = n; p.H = ob.in.h; p.W = ob.in.w; p.P = ob.P; p.Q = ob.Q; p.stride = ob.stride; p.M = n * ob.P * ob.Q;
     p.w2 = pb.w; p.w2_bytes = (unsigned)((size_t)pb.coutPad * pb.Kpad * 2); p.bias2 = pb.bias;
     p.w3 = pcn.w; p.w3_bytes = (unsigned)((size_t)pcn.coutPad * pcn.Kpad * 2); p.bias3 = pcn.bias;
-    p.res = oc.res.d; p.y = oc.out.d;
-    if (pb.Kpad != 9 * pb.cout || pcn.Kpad != pb.cout || pcn.cout != 4 * pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: panel geometry mismatch at " + ob.name);
+    p.res = oc.dual ? nullptr : oc.res.d; p.y = oc.out.d;
+    if (oc.dual) {
+        const long long z2 = (const char*)oc.in2.zero - (const char*)oc.in2.d;
+        if (z2 < 0 || z2 >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+        p.x2 = oc.in2.d; p.x2_bytes = (unsigned)z2 + 16u; p.x2_img_stride = oc.in2.img_stride; p.W2 = oc.in2.w; p.C2 = oc.in2.c; p.stride2 = oc.stride2;
+    }
+    if (pb.Kpad != 9 * pb.cout || pcn.Kpad != pb.cout + (oc.dual ? oc.in2.c : 0) || pcn.cout != 4 * pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: panel geometry mismatch at " + ob.name);
     if (ob.chain_a >= 0) {
         const Op& oa = h->ops[ob.chain_a];
         const Panel& pa = h->panels[oa.panel];
@@ -2375,9 +2386,9 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 const Op& oc = h->ops[o.chain_c];
                 const int planes = h->panels[o.panel].cout;
                 const double px = (double)n * o.P * o.Q;
-                h->prof_labels[i] = std::string(bneck_symbol(planes, chain_tile_m(h, o, n), o.chain_a >= 0)) + ":" + o.name + "+" + oc.name;
+                h->prof_labels[i] = std::string(bneck_symbol(planes, chain_tile_m(h, o, n), o.chain_a >= 0, oc.dual)) + ":" + o.name + "+" + oc.name;
                 fl += oc.flops_per_img * n;
-                by = 2.0 * ((double)n * o.in.h * o.in.w * planes + px * 4.0 * planes * 2.0) + o.bytes_fixed + oc.bytes_fixed;
+                by = 2.0 * ((double)n * o.in.h * o.in.w * planes + px * 4.0 * planes * (oc.dual ? 1.0 : 2.0) + (oc.dual ? px * oc.in2.c : 0.0)) + o.bytes_fixed + oc.bytes_fixed;
                 if (o.chain_a >= 0) {
                     const Op& oa = h->ops[o.chain_a];
                     h->prof_labels[i] += "+" + oa.name;

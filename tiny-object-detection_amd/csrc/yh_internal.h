@@ -122,11 +122,17 @@ struct BneckParams {
     unsigned w1n_bytes;
     const float* bias1n;    // [planes]
     half_t* a_next;         // [M][planes] dense (nullptr: none)
+    // the stage's first block: no identity shortcut (res = nullptr); the expand conv's K continues over C2 channels of x2
+    // [n][H2][W2][C2] read at stride2, w3 = [4 planes][planes + C2], bias3 = bias_c + bias_d (ConvParams::x2's two-source form)
+    const half_t* x2;
+    unsigned x2_bytes;
+    long long x2_img_stride;
+    int W2, C2, stride2;
     int grid_cap;           // > 0: persistent grid of at most this many workgroups (each walks its tiles); 0: one workgroup per tile
     int stagger;            // > 0: the second-dispatched half of the grid starts this many 64-clock sleep units late (phase offset)
 };
 hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream);
-const char* bneck_symbol(int planes, int tm, bool next);
+const char* bneck_symbol(int planes, int tm, bool next, bool dual = false);
 
 // Fused stem: 7x7 stride-2 conv (3 -> 64 channels, bias, ReLU) + 3x3 stride-2 max pool, one kernel.
 struct StemPoolParams {

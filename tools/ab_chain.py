@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tiny-object-detection_amd"))
 import yolact_amd as ya  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-variants = [int(v) for v in sys.argv[2:]] or [0, 1, 5, 13, 3]
+variants = [int(v) for v in sys.argv[2:]] or [0, 1, 65]
 frames = np.random.default_rng(0).integers(0, 256, (batch, 550, 550, 3), dtype=np.uint8)
 engs = {}
 blob = None
@@ -33,5 +33,5 @@ for r in range(rounds):
 for v in variants:
     a = np.array(t[v])
     desc = "off" if not v & 1 else ("on" + (", 128-px tile for 64 planes" if v & 2 else "") + (", persistent grid" if v & 4 else ", one WG per tile") +
-                                    (f", stagger {(v >> 8) * 64 if v >> 8 else 704} x 64 clk" if v & 8 else ""))
+                                    (f", stagger {(v >> 8) * 64 if v >> 8 else 704} x 64 clk" if v & 8 else "") + (", layer 1 only" if v & 32 else "") + (", no first-block form" if v & 64 else ""))
     print(f"chain={v:5d} ({desc}): median {np.median(a):.4f} ms/step, min {a.min():.4f}  -> {batch / np.median(a) * 1e3:.1f} frames/s", flush=True)
