@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     constexpr int WT2_BYTES = (KT + KT2) * 64 * 128, BT_BYTES = KT * TM * 128;
     constexpr int A_BYTES = bmax<P1_BYTES, WT2_BYTES + BT_BYTES>::v;
     constexpr int ST_BYTES = TM * 128, WT3_BYTES = NEXT ? PL * 128 : 0, X2_BYTES = KT2 * TM * 128;
-    constexpr int LDS_BYTES = A_BYTES + ST_BYTES + WT3_BYTES + X2_BYTES;
+    // (phase 1 double-buffers its k-step tiles over regions A + stage + Wt3, which are idle until phase 2: X2t stays clear of them)
+    constexpr int LDS_BYTES = bmax<A_BYTES + ST_BYTES + WT3_BYTES, 2 * P1_BYTES>::v + X2_BYTES;
+    static_assert(A_BYTES + ST_BYTES + WT3_BYTES >= 2 * P1_BYTES || X2_BYTES == 0, "the second source's tile must not overlap phase 1's second buffer");
     constexpr int LDW3 = PL + 64 * KT2;             // row stride of the expand conv's panel ([W_c | W_d] in the two-source form)
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -153,37 +155,44 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     {
         const unsigned wbase = (unsigned)((rb * (9 * PL) + lc * 8) * 2);
-        for (int kc = 0; kc < PL; kc += 64)
-            for (int r = 0; r < 3; ++r)
-                for (int s = 0; s < 3; ++s) {
-                    if (kc | r | s) __syncthreads();           // every wave is done reading the previous step's tiles
-                    lds_char* const dstw = lds3 + wave * 1024;
-                    const int wk = (r * 3 + s) * PL + kc;      // K index of this step in the [(r, s, c)] panel
+        // Two LDS stages: the DMA of step t + 1 is issued before the MFMAs of step t and lands underneath them; one barrier per
+        // step (vmcnt(0) + s_barrier: tile t + 1 has landed, every wave is done reading tile t). Same k order, same bits.
+        constexpr int NS = 9 * KT;
+        auto issue = [&](int t, int buf) {
+            const int kc = (t / 9) * 64, tap = t - (t / 9) * 9, r = tap / 3, s_ = tap - r * 3;
+            lds_char* const dstw = lds3 + buf * P1_BYTES + wave * 1024;
+            const int wk = (r * 3 + s_) * PL + kc;      // K index of this step in the [(r, s, c)] panel
 #pragma unroll
-                    for (int d = 0; d < WL; ++d)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, dstw + d * 4096, 16, (int)(wbase + (unsigned)((32 * d) * (9 * PL) + wk) * 2u), 0, 0, 0);
-                    const int toff = (r * p.W + s) * PL + kc;
+            for (int d = 0; d < WL; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, dstw + d * 4096, 16, (int)(wbase + (unsigned)((32 * d) * (9 * PL) + wk) * 2u), 0, 0, 0);
+            const int toff = (r * p.W + s_) * PL + kc;
 #pragma unroll
-                    for (int d = 0; d < XL; ++d) {
-                        const bool ok = (unsigned)(xih[d] + r) < (unsigned)p.H && (unsigned)(xiw[d] + s) < (unsigned)p.W;
-                        const unsigned voff = ok ? (unsigned)(xbase[d] + toff) * 2u : p.a_zero_off;   // padded taps read the allocation's zero block
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dstw + PL * 128 + d * 4096, 16, (int)voff, 0, 0, 0);
-                    }
-                    __syncthreads();                           // vmcnt(0) + barrier: the tiles have landed and are visible
+            for (int d = 0; d < XL; ++d) {
+                const bool ok = (unsigned)(xih[d] + r) < (unsigned)p.H && (unsigned)(xiw[d] + s_) < (unsigned)p.W;
+                const unsigned voff = ok ? (unsigned)(xbase[d] + toff) * 2u : p.a_zero_off;   // padded taps read the allocation's zero block
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dstw + PL * 128 + d * 4096, 16, (int)voff, 0, 0, 0);
+            }
+        };
+        issue(0, 0);
+        __syncthreads();
+        for (int t = 0; t < NS; ++t) {
+            const char* const base = lds + (t & 1) * P1_BYTES;
+            if (t + 1 < NS) issue(t + 1, (t + 1) & 1);
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int co = ((2 * kk + lh) ^ swz) << 4;
-                        half8 fa[TC], fb[TMT];
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((2 * kk + lh) ^ swz) << 4;
+                half8 fa[TC], fb[TMT];
 #pragma unroll
-                        for (int i = 0; i < TC; ++i) fa[i] = *(const half8*)(lds + a1_row + i * 4096 + co);
+                for (int i = 0; i < TC; ++i) fa[i] = *(const half8*)(base + a1_row + i * 4096 + co);
 #pragma unroll
-                        for (int j = 0; j < TMT; ++j) fb[j] = *(const half8*)(lds + PL * 128 + b1_row + j * 4096 + co);
+                for (int j = 0; j < TMT; ++j) fb[j] = *(const half8*)(base + PL * 128 + b1_row + j * 4096 + co);
 #pragma unroll
-                        for (int i = 0; i < TC; ++i)
+                for (int i = 0; i < TC; ++i)
 #pragma unroll
-                            for (int j = 0; j < TMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                    }
-                }
+                    for (int j = 0; j < TMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();   // region A is reused
     // the expand conv's weight k-tiles of chunk 0 (rows 0 .. 63 of W_c) travel while b is rounded into LDS

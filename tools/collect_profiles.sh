@@ -4,7 +4,7 @@
 #   PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) -> traffic JSON, SQ counters of the conv kernels.
 # Usage (inside gpurun): bash tools/collect_profiles.sh r01     -> writes gpurun_out/profiles_r01/
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -19,16 +19,20 @@ python3 $R/tools/make_traffic.py $F $W 64 $OUT/${TAG}_traffic.json > /dev/null
 cp $OUT/${TAG}_traffic.json $R/profiles/${TAG}_traffic.json   # bench.py reads roofline.traffic from profiles/
 echo "[3/6] bench"; python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 echo "[4/6] rocprofv3 kernel stats of the bench command"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+# (the batch-64 leg alone: the kernel averages of this CSV are then the headline step's own, as the bench line's roofline is)
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-batch1 --no-configs4 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp "$(find $OUT/stats -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats.csv
 echo "[5/6] per-launch tables, the configs[4] lines, the reference-path timings"
 python3 $R/tools/profile_table.py --batch 64 > $OUT/${TAG}_hipevent_per_launch_batch64.txt
 python3 $R/tools/profile_table.py --batch 1 > $OUT/${TAG}_hipevent_per_launch_batch1.txt
 python3 $R/tools/profile_table.py --backbone 101 --size 700 --batch 64 --precision fp8 > $OUT/${TAG}_hipevent_per_launch_yolact700_r101_fp8_batch64.txt
 python3 $R/bench.py --backbone 101 --size 700 --precision fp8 --batch 64 --no-batch1 > $OUT/${TAG}_bench_yolact700_r101_fp8_batch64.json 2> $OUT/bench_fp8.err
-python3 $R/bench.py --backbone 101 --size 700 --batch 64 --no-batch1 --no-cpu-baseline > $OUT/${TAG}_bench_yolact700_r101_f16_batch64.json 2> $OUT/bench_r101.err
+python3 $R/bench.py --backbone 101 --size 700 --batch 64 --no-batch1 --no-configs4 --no-cpu-baseline > $OUT/${TAG}_bench_yolact700_r101_f16_batch64.json 2> $OUT/bench_r101.err
 python3 $R/bench.py --backbone 101 --size 700 --precision fp8 --batch 8 --no-batch1 --no-cpu-baseline > $OUT/${TAG}_bench_yolact700_r101_fp8_batch8.json 2>> $OUT/bench_fp8.err
-{ python3 $R/tools/time_steps.py 1 2 4 8 16 32 64; python3 $R/tools/time_classify.py; python3 $R/tools/time_tflite.py; python3 $R/tools/time_scene.py; } > $OUT/${TAG}_timings.txt 2>&1
+{ python3 $R/tools/time_steps.py 1 2 4 8 16 32 64; python3 $R/tools/time_classify.py; python3 $R/tools/time_tflite.py; python3 $R/tools/time_scene.py; python3 $R/tools/time_h2d.py; } > $OUT/${TAG}_timings.txt 2>&1
+python3 $R/tools/ab_chain.py 64 0 1 65 > $OUT/${TAG}_ab_chain.txt 2>&1
+python3 $R/tools/fault_audit.py > $OUT/${TAG}_fault_audit_dump.txt 2>&1
+python3 $R/bench.py --gpus 2 --single-process --batch 32 --steps 10 --warmup 3 > $OUT/${TAG}_bench_single_process_2members.json 2> $OUT/bench_sp.err
 echo "[6/6] SQ counters"
 {
   echo "# rocprofv3 --pmc passes over tools/pmc_run.py 16 (batch 16, two eager forwards); sums over all dispatches of each kernel"
