@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
                 for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.0f;
     }
     const int a2_row = ((wave / W2M) * W2TC + l31) * 128, b2_row = ((wave % W2M) * W2TM + l31) * 128;
+#pragma unroll 1
     for (int oc = 0; oc < NOC; ++oc) {
         // S0: the residual rows of this chunk -> stage (they were requested one chunk ago); a' weights of this chunk on their way
         if (!KT2) {
@@ -249,35 +250,32 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
         }
         dma_wt3(oc);
         bar_vm<N3>();   // S1: Wt2(oc) has landed (issued before Wt3), the residual and (chunk 0) Bt are visible
-        // S2: chunk GEMM  acc2[64 ch][TM] = W_c[oc*64 .. +63][:] x b
-        f32x16 acc2[TC2][TMT2];
-#pragma unroll
-        for (int i = 0; i < TC2; ++i)
+        // S3 (early): request the next chunk's residual rows - resv was consumed at S0 - in flight until the next S0
+        if (oc + 1 < NOC) load_res(oc + 1);
+        // S2 + S4, one 32-channel half of the chunk at a time (half the accumulator registers: the whole chunk at once put the
+        // NEXT form at 256 VGPRs with spills, whose scratch reloads serialise against the hand-placed DMA):
+        //   acc2[32 ch][TM] = W_c[oc*64 + 32 i .. + 31][:] x [b ; x2], then y = relu(acc2 + bias_c (+ x)), rounded, in place over
+        //   the residual in stage (one lane per element). Every element sums its products in the same order as before.
+#pragma unroll 1
+        for (int i = 0; i < TC2; ++i) {
+            f32x16 acc2[TMT2];
 #pragma unroll
             for (int j = 0; j < TMT2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) acc2[j][e] = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < KT + KT2; ++kt)
+            for (int kt = 0; kt < KT + KT2; ++kt)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((2 * kk + lh) ^ swz) << 4;
-                half8 fa[TC2], fb[TMT2];
-                const char* const bsrc = kt < KT ? bt + kt * (TM * 128) : x2t + (kt - KT) * (TM * 128);   // b, then the second source
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int co = ((2 * kk + lh) ^ swz) << 4;
+                    half8 fb[TMT2];
+                    const char* const bsrc = kt < KT ? bt + kt * (TM * 128) : x2t + (kt - KT) * (TM * 128);   // b, then the second source
+                    const half8 fa = *(const half8*)(wt2 + kt * 8192 + a2_row + i * 4096 + co);
 #pragma unroll
-                for (int i = 0; i < TC2; ++i) fa[i] = *(const half8*)(wt2 + kt * 8192 + a2_row + i * 4096 + co);
+                    for (int j = 0; j < TMT2; ++j) fb[j] = *(const half8*)(bsrc + b2_row + j * 4096 + co);
 #pragma unroll
-                for (int j = 0; j < TMT2; ++j) fb[j] = *(const half8*)(bsrc + b2_row + j * 4096 + co);
-#pragma unroll
-                for (int i = 0; i < TC2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMT2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc2[i][j], 0, 0, 0);
-            }
-        // S3: request the next chunk's residual rows (in flight until the next S0)
-        if (oc + 1 < NOC) load_res(oc + 1);
-        // S4: y chunk = relu(acc2 + bias_c + x), rounded, in place over the residual in stage (one lane per element)
-#pragma unroll
-        for (int i = 0; i < TC2; ++i)
+                    for (int j = 0; j < TMT2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb[j], acc2[j], 0, 0, 0);
+                }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (wave / W2M) * W2TC + i * 32 + 8 * g + 4 * lh;   // channel within the chunk
@@ -291,13 +289,14 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
                     half4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc2[i][j][4 * g + e] + b4[e];
+                        float v = acc2[j][4 * g + e] + b4[e];
                         if (!KT2) v = v + (float)r4[e];
                         o[e] = (half_t)fmaxf(v, 0.0f);
                     }
                     *q = o;
                 }
             }
+        }
         // S5: the y chunk is complete; Wt3(oc) has landed (only the residual loads of S3 may still be in flight)
         if (oc + 1 < NOC && !KT2) bar_vm<XL>(); else bar_vm<0>();
         // S6: whole-row stores of the y chunk; the next chunk's expand weights; a' += W_a'[:, chunk] x y chunk
