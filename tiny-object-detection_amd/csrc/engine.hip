@@ -1038,8 +1038,8 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
 }
 int chain_tile_m(const yh_engine* h, const Op& ob, int n) {
     if (h->ops[ob.chain_c].dual) return ((long long)n * ob.P * ob.Q >= 8ll * h->tune.plan_cus * 128 || (h->tune.chain & 16)) ? 128 : 0;   // (one tile size; 0: inactive)
-    // (tune.chain bit 1, A/B: 128-pixel tiles for the 64-plane chains that also run the next block's conv - the form at the register limit)
-    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? (((h->tune.chain & 2) && ob.chain_a >= 0) ? 128 : 256) : 128;
+    // (tune.chain bit 1, A/B: 128-pixel tiles for the 64-plane chains: 48 KB of LDS and 160 VGPRs - three workgroups per CU)
+    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? ((h->tune.chain & 2) ? 128 : 256) : 128;
     const long long M = (long long)n * ob.P * ob.Q;
     // The big tiles from about four rounds of two workgroups per CU on: measured, the chain gains 1.6 % of a batch-64 step (9.3
     // rounds in layer 1) and LOSES 1.3 % at batch 16 (2.3 rounds: the long-lived workgroups' tail outweighs the saved traffic).
