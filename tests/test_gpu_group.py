@@ -36,7 +36,12 @@ class _Hip:
 
     def __init__(self):
         import ctypes as C
-        self.C, self.L = C, C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        import yolact_amd as ya
+        ya.load_library()
+        # the HIP runtime THIS process has already mapped (the one libyolact_hip.so bound to: /opt/rocm's, or torch's bundled copy
+        # when some earlier test imported torch first - opening the other one would clash with the loaded ROCr)
+        path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64.so" in ln), "libamdhip64.so")
+        self.C, self.L = C, C.CDLL(path)
         self.bufs, self.pinned = [], []
 
     def device(self, arr):
