@@ -662,14 +662,16 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #define SP_ST (2 * SP_PT + 1)   // stem tile edge (17)
 #define SP_NPX (SP_ST * SP_ST)  // 289
 #define SP_PR (2 * SP_ST + 5)   // input patch rows (39)
-#define SP_PC 40                // input patch columns (39 used), 8 bytes each
-#define SP_SS 144               // staging row stride in bytes (64 ch f16 = 128 + 16: conflict-free 8-byte column writes)
+#define SP_PC 42                // input patch columns (40 used), 8 bytes each
+#define SP_SS 184               // staging row stride in bytes (64 ch f16 = 128 + 56)
+// LDS images are laid out against bank conflicts by the lane-group rules of ds_read_b128 / ds_write_b64 (tools/study/
+// stem_lds_banks.py counts them): the 19 groups of 16 stem pixels are the 17 tile rows (columns 0 .. 15) plus column 16 in two
+// groups, so a group never wraps over a row; with 42 patch columns (row pitch 336 B) and a 184-byte staging pitch every B
+// fragment read and every staging write is conflict free and the pool's reads are 2-way (before: 289 pixels taken 16 at a
+// time, pitches 40 / 144 - 1.8-way, 1.9-way and 3-way; SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).
 __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) {
     __shared__ __attribute__((aligned(16))) char patch[SP_PR * SP_PC * 8];
     __shared__ __attribute__((aligned(16))) char stage[SP_NPX * SP_SS];
-    // fused preprocessing: (v - mean) / std rounded to f16, tabulated once per workgroup for the 256 byte values
-    // of each channel with the preprocess kernel's own expression (six divisions per fetched chunk otherwise)
-    __shared__ half_t norm_lut[3 * 256];
     typedef float accv __attribute__((ext_vector_type(4)));
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lh = lane >> 4;
@@ -684,16 +686,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) bias4[ct] = *(const f32x4*)(p.bias + (ct0 + ct) * 16 + 4 * lh);
 
-    if (p.rgb) {
-        const float mean[3] = { 123.68f, 116.78f, 103.94f }, sd[3] = { 58.40f, 57.12f, 57.38f };
-        for (int e = tid; e < 3 * 256; e += 512) norm_lut[e] = (half_t)(((float)(e & 255) - mean[e >> 8]) / sd[e >> 8]);
-        __syncthreads();
-    }
     const int tiles_img = p.tiles_y * p.tiles_x, total = p.n * tiles_img;
     constexpr int NCH = SP_PR * (SP_PC / 2), NLD = (NCH + 511) / 512;   // 16-byte patch chunks, per-thread slots
     half8 nv[NLD];
+    unsigned raw[NLD][2];   // rgb form: two pixels' raw bytes (c0 | c1 << 8 | c2 << 16 | valid << 24) - converted in store_patch
     // the next tile's patch travels through registers: loads are issued before this tile's MFMA
-    // phase and land in LDS after it, so their latency hides under the compute
+    // phase and land in LDS after it, so their latency hides under the compute (the rgb form keeps the RAW bytes over the
+    // MFMA phase and normalises them in store_patch)
     auto fetch_patch = [&](int tile) {
         const int b = tile / tiles_img, rem = tile - b * tiles_img;
         const int by0 = 4 * ((rem / p.tiles_x) * SP_PT) - 2, bx0 = 4 * ((rem % p.tiles_x) * SP_PT) - 2;   // even column
@@ -702,28 +701,45 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
             const int gy = by0 + row, gx = bx0 + 2 * cp;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) nv[k][e] = (half_t)0.0f;
-            if (p.rgb) {   // fused preprocessing: two pixels of raw RGB -> (v - mean) / std in f16, zero outside the image
+            const bool used = i < NCH && cp < 20;   // (columns 40, 41 are pitch only)
+            if (p.rgb) {   // fused preprocessing: two pixels of raw RGB, zero outside the image
                 const int iy = gy - 3;
-                if (i < NCH && (unsigned)iy < (unsigned)p.S) {
+                raw[k][0] = raw[k][1] = 0u;
+                if (used && (unsigned)iy < (unsigned)p.S) {
                     const uint8_t* row = p.rgb + ((long long)b * p.S + iy) * p.S * 3;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
                         const int ix = gx + px - 3;
-                        if ((unsigned)ix < (unsigned)p.S) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) nv[k][px * 4 + c] = norm_lut[c * 256 + row[ix * 3 + c]];
-                        }
+                        if ((unsigned)ix < (unsigned)p.S)
+                            raw[k][px] = (unsigned)row[ix * 3] | ((unsigned)row[ix * 3 + 1] << 8) | ((unsigned)row[ix * 3 + 2] << 16) | (1u << 24);
                     }
                 }
-            } else if (i < NCH && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp) nv[k] = *(const half8*)(img + ((long long)gy * p.Wp + gx) * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nv[k][e] = (half_t)0.0f;
+                if (used && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp) nv[k] = *(const half8*)(img + ((long long)gy * p.Wp + gx) * 4);
+            }
         }
     };
     auto store_patch = [&]() {
+        // (v - mean) / std rounded to f16 (the preprocess kernel's expression) as (v - mean) * (1 / std): the same f16 for every
+        // byte value of every channel (tests/test_stem_norm.py checks all 768), and no table read with its bank conflicts
+        const float mean[3] = { 123.68f, 116.78f, 103.94f }, rs[3] = { 1.0f / 58.40f, 1.0f / 57.12f, 1.0f / 57.38f };
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
+            if (p.rgb) {
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const bool ok = (raw[k][px] >> 24) != 0u;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = (float)((raw[k][px] >> (8 * c)) & 255u);
+                        nv[k][px * 4 + c] = ok ? (half_t)((v - mean[c]) * rs[c]) : (half_t)0.0f;
+                    }
+                    nv[k][px * 4 + 3] = (half_t)0.0f;
+                }
+            }
             if (i < NCH) *(half8*)(patch + (row * SP_PC + 2 * cp) * 8) = nv[k];
         }
     };
@@ -734,10 +750,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
         const int next = tile + gridDim.x;
         __syncthreads();   // patch visible; the previous tile's pool phase is done with the staging image
         if (next < total) fetch_patch(next);
-        for (int mt = wp; mt < (SP_NPX + 15) / 16; mt += 4) {
-            const int m = mt * 16 + l15;
-            const bool in_tile = m < SP_NPX;
-            const int mi = in_tile ? m / SP_ST : SP_ST - 1, mj = in_tile ? m - mi * SP_ST : SP_ST - 1;
+        for (int mt = wp; mt < SP_ST + 2; mt += 4) {
+            // group mt < 17: stem row mt, columns 0 .. 15; group 17: column 16, rows 0 .. 15; group 18: pixel (16, 16)
+            const bool in_tile = mt < SP_ST + 1 || l15 == 0;
+            const int mi = mt < SP_ST ? mt : (mt == SP_ST ? l15 : SP_ST - 1), mj = mt < SP_ST ? l15 : SP_ST - 1;
+            const int m = mi * SP_ST + mj;
             accv acc[2];   // start from the bias: one rounding fewer than (sum) + bias, and no separate add
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)

@@ -19,6 +19,10 @@ def symbol(name):
         if len(a) >= 11 and a[10] == "1":                          # fp8 operands: the engine's label for this instantiation
             return f"conv_igemm_fp8<{','.join(a[:4])}>{ml}{tail}"
         return f"conv_igemm_f16<{s}>{ml}{tail}"
+    m = re.search(r"bneck_chain_f16<([^>]*)>", name)   # <PL, TM, wave grids x4, NEXT, KT2>: the engine's label (bneck.hip: bneck_symbol)
+    if m:
+        a = [{"false": "0", "true": "1"}.get(x.strip(), x.strip()) for x in m.group(1).split(",")]
+        return "bneck_chain_f16<%s,%s%s%s>" % (a[0], a[1], ",next" if len(a) > 6 and a[6] == "1" else "", ",dual" if len(a) > 7 and a[7] != "0" else "")
     m = re.search(r"(?:yh::|_ZN2yh\d+)([a-z_0-9]+)", name)
     return m.group(1) if m else name[:40]
 
@@ -36,7 +40,7 @@ write, nw = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
     launches = max(nf[k], nw[k])
-    if not launches or not k.startswith(("conv_igemm", "conv_rowpatch", "stem_pool", "splitk", "det_", "bilinear", "maxpool", "preprocess")):
+    if not launches or not k.startswith(("conv_igemm", "bneck_chain", "conv_rowpatch", "stem_pool", "splitk", "det_", "bilinear", "maxpool", "preprocess")):
         continue
     fb = fetch[k] * 1024 * 2 / max(nf[k], 1)
     wb = write[k] * 1024 / max(nw[k], 1)
