@@ -107,11 +107,12 @@ typedef struct yh_tuning {
     int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
     int32_t chain;           /* identity bottleneck blocks of layers 1-2 as ONE launch each: 3x3 conv + 1x1 expand conv with the residual
                               * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches). Bit 0
-                              * on (default 1), bit 1 128-pixel tiles for 64 planes, bit 2 a persistent grid (two workgroups per CU) instead
+                              * on, bit 1 128-pixel tiles for 64 planes, bit 2 a persistent grid (two workgroups per CU) instead
                               * of one workgroup per tile, bit 3 (with bit 2) a phase stagger between co-resident workgroups, bit 4
-                              * also fuse launches that only fill 64-pixel tiles (small batches: slower, a test hook), bits 8..
-                              * the stagger in units of 4096 clocks. Bits 1-3 are measured A/B forms, all slower than the default; bit 5
-                              * layer 1 only, bit 6 without the fused form of layer 1's FIRST block (projection shortcut) */
+                              * also fuse launches that only fill 64-pixel tiles (small batches: 3 % faster at batch 1-8), bits 8..
+                              * the stagger in units of 4096 clocks. Default 17 (bits 0 and 4). Bits 1-3 are measured A/B forms, all
+                              * slower than the default; bit 5 layer 1 only, bit 6 without the fused form of layer 1's FIRST block
+                              * (projection shortcut) */
 } yh_tuning;
 
 typedef struct yh_config {

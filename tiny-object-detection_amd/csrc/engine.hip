@@ -138,7 +138,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
-    r.chain = d(t.chain, 1);
+    r.chain = d(t.chain, 17);
     return r;
 }
 
@@ -1016,8 +1016,9 @@ bool conv_absorbed(yh_engine* h, const Op& o, int n) {
 int chain_tile_m(const yh_engine* h, const Op& ob, int n);
 bool chain_active(const yh_engine* h, const Op& ob, int n) {
     if (!(h->tune.chain & 1) || h->cfg.debug_tensors || ob.chain_c < 0 || n < 1) return false;
-    // Launches too small for two big tiles per CU stay separate: with few, long-lived workgroups the serial chain is slower than
-    // three short launches (batch 1: 0.723 vs 0.711 ms per step with 64-pixel tiles). tune.chain bit 4 fuses them anyway (tests).
+    // Launches too small for the big tiles fuse on 64-pixel tiles (tune.chain bit 4, part of the default): per step, interleaved
+    // A/B in one process, batch 1: 0.717 -> 0.696 ms, 2: 0.922 -> 0.911, 4: 1.326 -> 1.269, 8: 1.992 -> 1.921, 16 and 32: equal
+    // within 0.2 % (the first version of the kernel, whose chunk loop spilled, had lost at batch 1: 0.723 vs 0.711).
     const int ctm = chain_tile_m(h, ob, n);
     if (ctm == 0 || (ctm == 64 && !(h->tune.chain & 16))) return false;
     const Op& oc = h->ops[ob.chain_c];
