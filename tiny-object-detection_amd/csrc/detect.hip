@@ -351,10 +351,6 @@ __global__ __launch_bounds__(1024) void det_frame_top(const DetectParams p) {
 
 #define YH_DETS_MAX 128
 
-// PPL: prototype pixels per lane. 4 (when the prototype plane's pixel count is a multiple of 4): a lane owns four
-// consecutive pixels and writes its four mask bytes as one dword - a wave's store is 256 contiguous bytes instead of 64 (the
-// masks are 122 MB per batch-64 step, the kernel's largest stream). Each pixel's sum is the same fma chain either way.
-template <int PPL>
 __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     __shared__ float coef[YH_DETS_MAX * 32];
     __shared__ float4 crop[YH_DETS_MAX];
@@ -368,21 +364,17 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     for (int d = tid; d < nd; d += 256) crop[d] = *(const float4*)(p.det_crop + ((long long)b * p.max_dets + d) * 4);
     __syncthreads();
     const int npx = p.hp * p.wp;
-    const int px = (blockIdx.x * 256 + tid) * PPL;
+    const int px = blockIdx.x * 256 + tid;
     if (px >= npx) return;
-    float fx[PPL], fy[PPL];
-    float pv[PPL][32];
+    const int y = px / p.wp, x = px - y * p.wp;
+    const float fx = (float)x, fy = (float)y;
+    float pv[32];
+    const half_t* pp = p.proto + ((long long)b * npx + px) * 32;
 #pragma unroll
-    for (int u = 0; u < PPL; ++u) {
-        const int y = (px + u) / p.wp, x = (px + u) - y * p.wp;
-        fx[u] = (float)x; fy[u] = (float)y;
-        const half_t* pp = p.proto + ((long long)b * npx + px + u) * 32;
+    for (int q = 0; q < 4; ++q) {
+        const half8 v = *(const half8*)(pp + q * 8);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const half8 v = *(const half8*)(pp + q * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pv[u][q * 8 + e] = (float)v[e];
-        }
+        for (int e = 0; e < 8; ++e) pv[q * 8 + e] = (float)v[e];
     }
     uint8_t* mo = p.masks + (long long)b * p.max_dets * npx + px;
     // small batches: the detections are dealt over gridDim.z groups so that more than hp*wp/256
@@ -391,28 +383,14 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     const int d0 = (int)blockIdx.z * per, d1 = d0 + per < nd ? d0 + per : nd;
     for (int d = d0; d < d1; ++d) {
         const float4 c = crop[d];
-        bool inside[PPL], any = false;
-#pragma unroll
-        for (int u = 0; u < PPL; ++u) { inside[u] = fx[u] >= c.x && fx[u] < c.y && fy[u] >= c.z && fy[u] < c.w; any = any || inside[u]; }
-        float acc[PPL];
-#pragma unroll
-        for (int u = 0; u < PPL; ++u) acc[u] = 0.0f;
-        if (__ballot(any) != 0ull) {   // wave-uniform: no pixel of this wave lies in the crop window -> all zeros
+        const bool inside = fx >= c.x && fx < c.y && fy >= c.z && fy < c.w;
+        float acc = 0.0f;
+        if (__ballot(inside) != 0ull) {   // wave-uniform: no lane of these 64 pixels lies in the crop window -> all zeros
             const float* co = coef + d * 32;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float ck = co[k];
-#pragma unroll
-                for (int u = 0; u < PPL; ++u) acc[u] = __fmaf_rn(pv[u][k], ck, acc[u]);
-            }
+            for (int k = 0; k < 32; ++k) acc = __fmaf_rn(pv[k], co[k], acc);
         }
-        if (PPL == 1) mo[(long long)d * npx] = (uint8_t)((inside[0] && acc[0] > 0.0f) ? 1 : 0);
-        else {
-            unsigned m4 = 0;
-#pragma unroll
-            for (int u = 0; u < PPL; ++u) m4 |= ((inside[u] && acc[u] > 0.0f) ? 1u : 0u) << (8 * u);
-            *(unsigned*)(mo + (long long)d * npx) = m4;
-        }
+        mo[(long long)d * npx] = (uint8_t)((inside && acc > 0.0f) ? 1 : 0);
     }
 }
 
@@ -433,14 +411,7 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
         }
         case 1: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL(det_frame_top, dim3((unsigned)p.n), dim3(1024), 0, s, p); break;
-        case 3: {
-            const int npx = p.hp * p.wp;
-            const unsigned gz = p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u);
-            // four pixels per lane where the planes allow dword stores and the batch still fills the chip with a quarter of the workgroups
-            if (npx % 4 == 0 && (long long)p.n * npx >= 4ll * 256 * 1024) hipLaunchKernelGGL(det_masks<4>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)p.n, gz), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(det_masks<1>, dim3((unsigned)((npx + 255) / 256), (unsigned)p.n, gz), dim3(256), 0, s, p);
-            break;
-        }
+        case 3: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
