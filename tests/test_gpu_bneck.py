@@ -23,15 +23,20 @@ def _pair(ya, n, **tune):
 DUAL = "bneck_chain_f16<64,128,next,dual"
 
 
-@pytest.mark.parametrize("n,tune,want,chains,nexts", [
-    (1, {"chain": 17}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL}, 6, 4),            # batch 1: the small tiles (test hook: bit 4)
-    (8, {"plan_cus": 64, "chain": 17}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64", DUAL}, 6, 4),   # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
-    (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128", DUAL}, 6, 4),       # planned for a 32-CU chip: both big tiles + the first-block form (the default plan of a batch-64 step)
-    (8, {"plan_cus": 32, "chain": 65}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 5, 3),   # without the first-block form (bit 6)
-    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 6, 4),   # persistent grid + phase stagger (A/B forms)
-    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}, 6, 4),                            # the 128-pixel form of the 64-plane tile
+XN = "bneck_xn_f16"
+
+
+@pytest.mark.parametrize("n,tune,want,chains,nexts,xn", [
+    (1, {}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL}, 6, 4, 0),                         # batch 1: the small tiles
+    (8, {}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL, XN}, 6, 4, 4),                     # batch 8: ... and layer 3's expand + next-reduce launches (154 tiles: more than half a round, at most one)
+    (8, {"chain": 17 + 128}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL}, 6, 4, 0),        # ... without them (bit 7)
+    (8, {"plan_cus": 64}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64", DUAL}, 6, 4, 0),          # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
+    (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128", DUAL}, 6, 4, 0),         # planned for a 32-CU chip: both big tiles + the first-block form (the default plan of a batch-64 step)
+    (8, {"plan_cus": 32, "chain": 65}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 5, 3, 0),  # without the first-block form (bit 6)
+    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 6, 4, 0),  # persistent grid + phase stagger (A/B forms)
+    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}, 6, 4, 0),                              # the 128-pixel form of the 64-plane tile
 ])
-def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains, nexts):
+def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains, nexts, xn):
     import yolact_amd as ya
     f, u = _pair(ya, n, **tune)
     rng = np.random.default_rng(100 + n)
@@ -40,12 +45,15 @@ def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains
         for e in (f, u):
             e.set_input(frames); e.evaluate()
         names = [p["name"] for p in f.profile(with_tail=True, reps=1)]
-        got = {nm.split(":")[0].replace(",next>", "").rstrip(">") for nm in names if nm.startswith("bneck_chain")}
+        got = {nm.split(":")[0].replace(",next>", "").rstrip(">") for nm in names if nm.startswith("bneck_")}
         assert {w for w in want} <= got, (want, got)
         # the chains of R50's layers 1-2: l1b0 (first block, + l1b1_a), l1b1 (+ l1b2_a), l1b2, l2b1 (+ l2b2_a), l2b2 (+ l2b3_a), l2b3
+        # ... and of layer 3 (256 planes: the 3x3 conv stays a launch of its own): l3b1 (+ l3b2_a) ... l3b4 (+ l3b5_a)
+        n_xn = sum(nm.startswith("bneck_xn") for nm in names)
+        assert n_xn == xn, names
         assert sum(nm.startswith("bneck_chain") for nm in names) == chains and sum(",next" in nm for nm in names) == nexts, names
-        assert len(names) == len(u.profile(with_tail=True, reps=1)) - chains - nexts
-        for name in ("l1b0", "l1b1_a", "l1b1", "c2", "l1b2_a", "l2b1", "l2b2_a", "l2b3_a", "c3", "c4", "c5", "p3", "proto2"):
+        assert len(names) == len(u.profile(with_tail=True, reps=1)) - chains - nexts - xn
+        for name in ("l1b0", "l1b1_a", "l1b1", "c2", "l1b2_a", "l2b1", "l2b2_a", "l2b3_a", "c3", "l3b1", "l3b2_a", "l3b4", "l3b5_a", "c4", "c5", "p3", "proto2"):
             for fr in (0, n - 1):
                 assert np.array_equal(f.tensor_frame(name, fr), u.tensor_frame(name, fr)), (name, fr, rep)
         for i in range(4):

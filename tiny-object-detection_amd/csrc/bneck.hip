@@ -45,6 +45,20 @@ template <int A, int B>
 struct bmax { static constexpr int v = A > B ? A : B; };
 
 // vmcnt(N) (all but the N youngest vector-memory operations of this wave have completed), lgkmcnt(0), workgroup barrier.
+// Four bias values bias[base8 + 4 lh .. + 3] (base8 wave-uniform, a multiple of 8) through the SCALAR cache: the constant address
+// space makes the uniform-index loads s_load_dwordx8 (lgkmcnt), and the lane picks its half. A vector load here would be one more
+// vmcnt entry YOUNGER than the residual rows and weight tiles requested ahead, and the wait in front of its use (vmcnt(0) - seen
+// in the ISA after every bias load of the first version) made each chunk wait for the next chunk's residual rows to arrive
+// from HBM: the prefetch undone.
+typedef const __attribute__((address_space(4))) float cfloat_t;
+__device__ __forceinline__ f32x4 bias_quad(const float* bias, int base8, int lh) {
+    cfloat_t* const b = (cfloat_t*)(unsigned long long)bias;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = b[base8 + e]; hi[e] = b[base8 + 4 + e]; }
+    return lh ? hi : lo;
+}
+
 template <int N>
 __device__ __forceinline__ void bar_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (wave / WM) * WTC + i * 32 + 8 * g + 4 * lh;
-                const f32x4 b4 = *(const f32x4*)(p.bias2 + ch);
+                const f32x4 b4 = bias_quad(p.bias2, (wave / WM) * WTC + i * 32 + 8 * g, lh);
 #pragma unroll
                 for (int j = 0; j < TMT; ++j) {
                     const int m = (wave % WM) * WTM + j * 32 + l31;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (wave / W2M) * W2TC + i * 32 + 8 * g + 4 * lh;   // channel within the chunk
-                const f32x4 b4 = *(const f32x4*)(p.bias3 + oc * 64 + ch);
+                const f32x4 b4 = bias_quad(p.bias3, oc * 64 + (wave / W2M) * W2TC + i * 32 + 8 * g, lh);
 #pragma unroll
                 for (int j = 0; j < TMT2; ++j) {
                     const int m = (wave % W2M) * W2TM + j * 32 + l31;
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (wave / WM) * WTC + i * 32 + 8 * g + 4 * lh;
-                const f32x4 b4 = *(const f32x4*)(p.bias1n + ch);
+                const f32x4 b4 = bias_quad(p.bias1n, (wave / WM) * WTC + i * 32 + 8 * g, lh);
 #pragma unroll
                 for (int j = 0; j < TMT; ++j) {
                     const int m = (wave % WM) * WTM + j * 32 + l31;
@@ -358,7 +372,230 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     }   // persistent tile loop
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// bneck_xn_f16 - the same idea for a 256-plane block (layer 3) WITHOUT its 3x3 conv: b is a tensor in memory (the 3x3 conv's
+// 1.2 MB of weights do not fit a chain, and in fp8 precision it is an fp8 launch of its own), and this launch computes
+//
+//   y  = relu(W_c b + bias_c + x)        256 -> 1024   (written: the next block's residual)
+//   a' = relu(W_a' y + bias_a')          1024 -> 256   (written: the next block's conv_b input; in fp8 precision also / only as E4M3)
+//
+// for one tile of 64 pixels per workgroup: two launches become one and y is not read back. What the workgroup moves most is
+// WEIGHTS - both panels, 1 MB, stream through LDS once per tile (64 KB per 64-channel chunk of y) - and what that costs is not L2
+// bandwidth (tools/exp/dma_probe.hip: 126 GB/s per CU) but ISSUE: an LDS-DMA instruction moves 1 KB and holds its wave for
+// 110-150 clocks here (in-kernel s_memtime stamps: 2 000-2 700 clocks per step for a wave's 18), during which that wave issues
+// nothing else. So the workgroup is EIGHT waves with two jobs:
+//   waves 0-3 (compute)  GEMM 2: acc2[32 ch x 32 px] = W_c tile x b; + bias + residual, ReLU, f16, in place into the stage |M|
+//                        their half of GEMM 3                                                                               |E|
+//   waves 4-7 (loaders)  step oc + 1's residual rows and W_c tile by LDS-DMA |M| the y chunk's whole-row stores out of the stage,
+//                        step oc + 1's W_a' tile by LDS-DMA, their half of GEMM 3, counted wait for what the next step needs |E|
+// (|M|, |E|: the step's two workgroup barriers; one wave of each kind per SIMD; GEMM 3: acc3[64 ch x 32 px] += W_a' tile x the
+// staged y chunk on all eight waves). The b tile is held in the compute waves'
+// REGISTERS as the expand conv's B fragments (64 VGPRs, loaded once), which leaves the LDS to two stages of every stream
+// (2 x 32 KB W_c rows [64][256], 2 x 32 KB W_a' columns [256][64], 2 x 8 KB stage) plus the biases: 149 KB, one workgroup per CU.
+// Inside the loop no vector-memory load returns to registers and the kernel has ONE __shared__ object: the compiler's own
+// s_waitcnt in front of a register load's use, or in front of a ds_read it cannot tell apart from an LDS-DMA target (separate
+// __shared__ arrays give it alias scopes to try), is vmcnt(0) - it would drain the next step's DMAs every step (seen in the ISA).
+//
+// Same MFMA products in the same order and the same f32 epilogue operations as the two separate launches: bit-identical to them
+// (tests/test_gpu_bneck.py).
+__global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
+    constexpr int PL = 256, TM = 64, KT = 4, C4 = 1024, NOC = 16;
+    constexpr int W2_BYTES = KT * 64 * 128, W3_BYTES = PL * 128, ST_BYTES = TM * 128;   // 32 KB, 32 KB, 8 KB
+    constexpr int ST_OFF = 2 * W2_BYTES + 2 * W3_BYTES, BIAS_OFF = ST_OFF + 2 * ST_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[BIAS_OFF + (C4 + PL) * 4];
+    float* const bias_c = (float*)(lds + BIAS_OFF);
+    float* const bias_n = bias_c + C4;
+    lds_char* const lds3 = (lds_char*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv >= 4;
+    const int wave = wv & 3, lt = tid & 255;
+    const int pc = lt & 7, rb = lt >> 3, lc = pc ^ ((rb >> 1) & 7);     // row-pass role: physical chunk pc of rows rb + 32 d holds logical chunk lc
+    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
+    const int wc = wave >> 1, wm = wave & 1;                            // compute waves: 2 x 2 (channel half x pixel half) in both GEMMs
+    const int m0 = blockIdx.x * TM;
+
+    if (tid < C4 / 4) *(f32x4*)(bias_c + tid * 4) = *(const f32x4*)(p.bias3 + tid * 4);
+    else if (tid < C4 / 4 + PL / 4) *(f32x4*)(bias_n + (tid - C4 / 4) * 4) = *(const f32x4*)(p.bias1n + (tid - C4 / 4) * 4);
+
+    // GEMM 3 on all eight waves: wave wv owns pixels 32 (wv & 1) .. + 31 and channels 64 (wv >> 1) .. + 63 of a'
+    const int a3_row = ((wv >> 1) * 64 + l31) * 128, b3_row = ((wv & 1) * 32 + l31) * 128;
+    f32x16 acc3[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc3[i][e] = 0.0f;
+    auto gemm3 = [&](const char* wt3, const char* stage) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((2 * kk + lh) ^ swz) << 4;
+            const half8 fb = *(const half8*)(stage + b3_row + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half8 fa = *(const half8*)(wt3 + a3_row + i * 4096 + co);
+                acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc3[i], 0, 0, 0);
+            }
+        }
+    };
+    auto wg_barrier = [&]() {   // lgkmcnt(0) + s_barrier
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    if (loader) {
+        const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
+        unsigned roff[2];   // this thread's two residual rows (rows past M read row 0: their results are not stored)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int m = m0 + rb + 32 * d;
+            roff[d] = (unsigned)(((m < p.M ? m : 0) * C4 + lc * 8) * 2);
+        }
+        auto dma_front = [&](int oc) {   // what GEMM 2 of step oc needs: the residual rows (into the stage) and the W_c tile
+            lds_char* const ds = lds3 + ST_OFF + (oc & 1) * ST_BYTES + wave * 1024;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, ds + d * 4096, 16, (int)(roff[d] + (unsigned)(oc * 128)), 0, 0, 0);
+            lds_char* const d2 = lds3 + (oc & 1) * W2_BYTES + wave * 1024;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, d2 + kt * 8192 + d * 4096, 16, (int)((unsigned)(((oc * 64 + rb + 32 * d) * PL + kt * 64 + lc * 8) * 2)), 0, 0, 0);
+        };
+        auto dma_back = [&](int oc) {    // what GEMM 3 of step oc needs: the W_a' tile
+            lds_char* const d3 = lds3 + 2 * W2_BYTES + (oc & 1) * W3_BYTES + wave * 1024;
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, d3 + d * 4096, 16, (int)((unsigned)(((rb + 32 * d) * C4 + oc * 64 + lc * 8) * 2)), 0, 0, 0);
+        };
+        dma_front(0);
+        dma_back(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (the W_a' tile may land under step 0's GEMM 2: the loop's first wait covers it)
+        wg_barrier();   // |E(-1)|: step 0's residual rows, its W_c tile and the biases are in LDS
+#pragma unroll 1
+        for (int oc = 0; oc < NOC; ++oc) {
+            const char* const stage = lds + ST_OFF + (oc & 1) * ST_BYTES;
+            // Counted waits (vmcnt completes in order): each stream is waited for half a step after it was requested.
+            if (oc + 1 < NOC) {
+                dma_front(oc + 1);   // 10 instructions (those buffers were released by |E(oc - 1)|)
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // all but these: this step's W_a' tile has landed
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier();   // |M(oc)|: the y chunk is complete in the stage, GEMM 3 may start
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int m = m0 + rb + 32 * d;
+                if (m < p.M) *(half8*)(p.y + (long long)m * C4 + oc * 64 + lc * 8) = *(const half8*)(stage + (rb + 32 * d) * 128 + pc * 16);
+            }
+            if (oc + 1 < NOC) dma_back(oc + 1);    // 8 instructions
+            gemm3(lds + 2 * W2_BYTES + (oc & 1) * W3_BYTES, stage);
+            if (oc + 1 < NOC) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // all but those 8: the stores are out, step oc + 1's residual rows and W_c tile have landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier();   // |E(oc)|
+        }
+    } else {
+        // b fragments of this wave's 32 pixels: k-tile kt, 16-deep slice kk -> channels kt * 64 + (2 kk + lh) * 8 .. + 7 of row wm * 32 + l31
+        half8 bf[KT][4];
+        {
+            const int mm = m0 + wm * 32 + l31;
+            const half_t* brow = p.a + (long long)(mm < p.M ? mm : 0) * PL + lh * 8;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bf[kt][kk] = *(const half8*)(brow + kt * 64 + kk * 16);
+        }
+        // (used here so that the compiler's wait for them stands in front of the loop, not inside it)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) asm volatile("" :: "v"(bf[kt][kk]));
+        const int a2_row = (wc * 32 + l31) * 128;
+        wg_barrier();   // |E(-1)|
+#pragma unroll 1
+        for (int oc = 0; oc < NOC; ++oc) {
+            const char* const wt2 = lds + (oc & 1) * W2_BYTES;
+            const char* const wt3 = lds + 2 * W2_BYTES + (oc & 1) * W3_BYTES;
+            char* const stage = lds + ST_OFF + (oc & 1) * ST_BYTES;
+            // GEMM 2: 32 channels x 32 pixels per wave, K = 256 out of the b fragments
+            f32x16 acc2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const half8 fa = *(const half8*)(wt2 + kt * 8192 + a2_row + (((2 * kk + lh) ^ swz) << 4));
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, bf[kt][kk], acc2, 0, 0, 0);
+                }
+            {   // all eight LDS reads of the epilogue first (issued under the MFMAs' tail), then the arithmetic, then the writes
+                const int m = wm * 32 + l31;   // pixel within the tile; channels wc * 32 + 8 g + 4 lh .. + 3 of the chunk
+                f32x4 b4[4];
+                half4 r4[4];
+                half4* q[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wc * 32 + 8 * g + 4 * lh;
+                    b4[g] = *(const f32x4*)(bias_c + oc * 64 + ch);
+                    q[g] = (half4*)(stage + m * 128 + (((ch >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2);
+                    r4[g] = *q[g];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[4 * g + e] + b4[g][e];
+                        v = v + (float)r4[g][e];
+                        o[e] = (half_t)fmaxf(v, 0.0f);
+                    }
+                    *q[g] = o;
+                }
+            }
+            wg_barrier();   // |M(oc)|
+            gemm3(wt3, stage);
+            wg_barrier();   // |E(oc)|
+        }
+    }
+    // a' = relu(acc3 + bias_a'), rounded, into the (dead) first weight stage as [4 k-tiles][64 rows][128 B]: all eight waves
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = (wv >> 1) * 64 + i * 32 + 8 * g + 4 * lh, m = (wv & 1) * 32 + l31;
+            const f32x4 b4 = *(const f32x4*)(bias_n + ch);
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf(acc3[i][4 * g + e] + b4[e], 0.0f);
+            *(half4*)(lds + (ch >> 6) * (TM * 128) + m * 128 + ((((ch & 63) >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2) = o;
+        }
+    wg_barrier();
+    // whole-row stores of a': k-tiles 2 (tid >> 8) and + 1
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int kt = 2 * (tid >> 8) + k2, m = m0 + rb + 32 * d;
+            if (m < p.M) {
+                const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
+                if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
+                if (p.a_next8) {   // fp8 precision: a' feeds an fp8 convolution (quantised from the f16-rounded value, as conv_igemm's epilogue)
+                    unsigned lo = 0, hi = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo |= e4m3_code((float)o[e] * p.a_next8_inv_scale) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv_scale) << (8 * e);
+                    }
+                    *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
+                }
+            }
+        }
+}
+
 const char* bneck_symbol(int planes, int tm, bool next, bool dual) {
+    if (planes == 256) return "bneck_xn_f16";
     if (dual) return "bneck_chain_f16<64,128,next,dual>";
     if (planes == 64 && tm == 128) return next ? "bneck_chain_f16<64,128,next>" : "bneck_chain_f16<64,128>";
     if (planes == 64) return tm == 256 ? (next ? "bneck_chain_f16<64,256,next>" : "bneck_chain_f16<64,256>") : (next ? "bneck_chain_f16<64,64,next>" : "bneck_chain_f16<64,64>");
@@ -372,6 +609,11 @@ hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t st
     const int slots = p.grid_cap > 0 ? p.grid_cap : ntiles;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     const bool next = p.a_next != nullptr;
+    if (p.no_b) {   // expand conv + residual + next reduce conv of a 256-plane block; b is a tensor (p.a)
+        if (planes != 256 || tm != 64 || p.x2 || !p.res || !p.w1n || (!p.a_next && !p.a_next8) || p.grid_cap) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bneck_xn_f16, grid, dim3(512), 0, stream, p);
+        return hipGetLastError();
+    }
     if (p.x2) {   // the stage's first block (two-source expand conv): 64 planes, 64-channel second source, 128-pixel tiles
         if (planes != 64 || tm != 128 || p.C2 != 64 || !next || p.res) return hipErrorInvalidValue;
         hipLaunchKernelGGL((bneck_chain_f16<64, 128, 1, 4, 1, 4, true, 1>), grid, dim3(256), 0, stream, p);

@@ -86,6 +86,9 @@ struct Op {
     // bottleneck chain (bneck.hip; tune.chain): on an identity block's 3x3 conv - the block's last 1x1 conv and (if any) the next
     // block's first 1x1 conv that run inside its launch; on those two - the 3x3 conv that absorbs them
     int chain_c = -1, chain_a = -1, in_chain = -1;
+    // ... the no-3x3 form (256 planes, layer 3): on the block's last 1x1 conv - the next block's first 1x1 conv that runs inside its
+    // launch; on that one - the conv that absorbs it
+    int xn_a = -1, in_xn = -1;
     int fused_into = -1;   // ... and on that 1x1 conv: the index of the conv that may absorb it
     bool side = false;     // may run on the second stream: nothing on the main stream reads its output before the step's join
     bool dual = false;     // two-source 1x1 form: K continues over `in2` read at `stride2` (ConvParams::x2)
@@ -500,6 +503,13 @@ int build_graph_spec(yh_engine* h) {
             ob.chain_a = blocks[i + 1].a;
             h->ops[blocks[i + 1].a].in_chain = bo.b;
         }
+    }
+    // 256-plane identity blocks (layer 3): expand conv + residual + the next block's reduce conv as one launch (xn_active)
+    for (size_t i = 0; i + 1 < blocks.size(); ++i) {
+        const BlockOps& bo = blocks[i];
+        if (!bo.identity || bo.planes != 256 || blocks[i + 1].stage != bo.stage) continue;
+        h->ops[bo.c].xn_a = blocks[i + 1].a;
+        h->ops[blocks[i + 1].a].in_xn = bo.c;
     }
     // ---- FPN
     for (int l = 0; l < 5; ++l) h->lvl[l] = l == 0 ? cfeat[1].h : out_dim(h->lvl[l - 1], 3, 2, 1);
@@ -1079,10 +1089,63 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
     return YH_OK;
 }
 
+// The no-3x3 form (bneck.hip: NOB): does the expand conv `oc` of a 256-plane identity block also run the next block's reduce conv
+// at batch n? One eight-wave workgroup per CU and 64-pixel tiles: for launches of about one tile per CU, where the two separate
+// launches are latency bound (YOLACT-700 R101 at 8 frames: 22 + 25 us -> one launch of 40). tune.chain bit 7 turns it off.
+bool xn_active(const yh_engine* h, const Op& oc, int n) {
+    if (!(h->tune.chain & 1) || (h->tune.chain & 128) || oc.xn_a < 0 || n < 1 || oc.kind != OP_CONV) return false;
+    const Panel& pc = h->panels[oc.panel];
+    const Op& oa = h->ops[oc.xn_a];
+    const Panel& pa = h->panels[oa.panel];
+    const long long pq = (long long)oc.P * oc.Q, M = (long long)n * pq;
+    // One round of tiles and at least half a round: measured per step, interleaved (tools/study/xn_ab_c4.py, tools/ab_tune.py):
+    // YOLACT-700 R101 fp8 at 8 frames (242 tiles) 3.242 -> 3.089 ms; YOLACT-550 R50 at batch 8 (154) 1.887 -> 1.876; but batch 4
+    // (77) 1.252 -> 1.272, batch 16 (307: two rounds) 3.076 -> 3.085, R101 at 12 frames (363) 4.572 -> 4.621. The launch is bound by
+    // the L2 -> LDS path (1 MB of weights per 64-pixel tile, ~40 us per round); the separate launches win once they fill the chip.
+    const long long tiles = (M + 63) / 64;
+    if (tiles > h->tune.plan_cus || 2 * tiles <= h->tune.plan_cus) return false;
+    if (pc.k != 1 || pc.Kpad != 256 || pc.cout != 1024 || oc.stride != 1 || oc.dual || oc.res_up || !oc.has_res || oc.act != 1 || oc.nlev > 0) return false;
+    if (oc.in.c != 256 || oc.in.img_stride != pq * 256 || oc.out.c != 1024 || oc.out.img_stride != pq * 1024 || oc.res.c != 1024 || oc.res.img_stride != pq * 1024) return false;
+    if (pa.k != 1 || pa.Kpad != 1024 || pa.cout != 256 || oa.stride != 1 || oa.dual || oa.has_res || oa.act != 1 || oa.out.c != 256 || oa.out.img_stride != pq * 256) return false;
+    if (oa.in.d != oc.out.d) return false;
+    if (h->fp8_active && (oc.fp8 || oa.fp8 || oc.write_q || !oc.write_f16)) return false;
+    return true;
+}
+int fill_xn_params(yh_engine* h, const Op& oc, int n, BneckParams* out) {
+    const Op& oa = h->ops[oc.xn_a];
+    const Panel &pc = h->panels[oc.panel], &pa = h->panels[oa.panel];
+    BneckParams p;
+    memset(&p, 0, sizeof p);
+    const long long zo = (const char*)oc.in.zero - (const char*)oc.in.d;
+    if (zo < 0 || zo >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv input exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+    p.no_b = 1;
+    p.a = oc.in.d; p.a_zero_off = (unsigned)zo; p.a_bytes = (unsigned)zo + 16u; p.a_img_stride = oc.in.img_stride;
+    p.N = n; p.H = oc.in.h; p.W = oc.in.w; p.P = oc.P; p.Q = oc.Q; p.stride = 1; p.M = n * oc.P * oc.Q;
+    p.w3 = pc.w; p.w3_bytes = (unsigned)((size_t)pc.coutPad * pc.Kpad * 2); p.bias3 = pc.bias;
+    p.res = oc.res.d; p.y = oc.out.d;
+    const long long zr = (const char*)oc.res.zero - (const char*)oc.res.d;
+    if (zr < 0 || zr >= 0xFFFFFF00ll) return h->fail(YH_EINVAL, "conv residual exceeds the 4 GiB buffer-descriptor range: lower max_batch");
+    p.res_bytes = (unsigned)zr + 16u;
+    p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias;
+    p.a_next = (!h->fp8_active || oa.write_f16) ? oa.out.d : nullptr;
+    if (h->fp8_active && oa.write_q) { p.a_next8 = oa.out.q; p.a_next8_inv_scale = 1.0f / h->act_scale[oa.out.sid]; }
+    *out = p;
+    return YH_OK;
+}
+
 int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
     hipError_t e = hipSuccess;
     if (o.kind == OP_CONV && conv_absorbed(h, o, n)) return YH_OK;
     if (o.kind == OP_CONV && o.in_chain >= 0 && chain_active(h, h->ops[o.in_chain], n)) return YH_OK;   // runs inside the chain's launch
+    if (o.kind == OP_CONV && o.in_xn >= 0 && xn_active(h, h->ops[o.in_xn], n)) return YH_OK;           // ... inside the previous block's last launch
+    if (o.kind == OP_CONV && xn_active(h, o, n)) {
+        BneckParams bp;
+        const int rc = fill_xn_params(h, o, n, &bp);
+        if (rc) return rc;
+        e = launch_bneck(bp, 256, 64, side ? h->side : h->stream);
+        if (e != hipSuccess) return h->fail(YH_EHIP, "bneck_chain_f16 (no 3x3):" + o.name + ": " + hipGetErrorString(e));
+        return YH_OK;
+    }
     if (o.kind == OP_CONV && chain_active(h, o, n)) {
         BneckParams bp;
         const int rc = fill_bneck_params(h, o, n, &bp);
@@ -2308,6 +2371,8 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         if (conv_absorbed(h, o, n)) continue;   // (accounted with the launch that computes it)
         if (o.in_chain >= 0 && chain_active(h, h->ops[o.in_chain], n)) continue;
         if (chain_active(h, o, n)) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }   // one launch: launch_op
+        if (o.in_xn >= 0 && xn_active(h, h->ops[o.in_xn], n)) continue;
+        if (xn_active(h, o, n)) { ProfEntry e{}; e.op = i; e.stage = -1; e.is_conv = false; out->push_back(e); continue; }
         ConvParams p;
         ConvTile tile;
         const int rc = fill_conv_params(h, o, n, &p, &tile);
@@ -2383,6 +2448,13 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                     fl += t.flops_per_img * n;
                     by += t.bytes_fixed + 2.0 * n * ((double)t.P * t.Q * h->panels[t.panel].cout - (double)o.P * o.Q * h->panels[o.panel].cout * (h->fp8_active && !o.write_f16 ? 0.0 : 1.0));
                 }
+            } else if (o.kind == OP_CONV && xn_active(h, o, n)) {
+                // expand conv + next reduce conv: both convolutions' FLOPs; HBM bytes = b + residual in, y + a' out, the weights
+                const Op& oa = h->ops[o.xn_a];
+                const double px = (double)n * o.P * o.Q;
+                h->prof_labels[i] = std::string(bneck_symbol(256, 64, true, false)) + ":" + o.name + "+" + oa.name;
+                fl += oa.flops_per_img * n;
+                by = 2.0 * px * (256.0 + 1024.0 + 1024.0) + px * 256.0 * ((oa.write_f16 || !h->fp8_active ? 2.0 : 0.0) + (h->fp8_active && oa.write_q ? 1.0 : 0.0)) + o.bytes_fixed + oa.bytes_fixed;
             } else if (o.kind == OP_CONV && chain_active(h, o, n)) {
                 // a bottleneck chain: the FLOPs of its two or three convolutions; HBM bytes = a + residual in, y (+ a') out, the weights
                 const Op& oc = h->ops[o.chain_c];

@@ -128,6 +128,12 @@ struct BneckParams {
     unsigned x2_bytes;
     long long x2_img_stride;
     int W2, C2, stride2;
+    // the no-3x3 form (256 planes): a = the block's conv_b OUTPUT [M][planes] (dense rows), w2 / bias2 unused; a' may (also) be
+    // written as E4M3 codes (fp8 precision: it feeds an fp8 convolution)
+    int no_b;
+    unsigned res_bytes;     // ... its residual rows travel by LDS-DMA: the buffer-descriptor range of res
+    uint8_t* a_next8;
+    float a_next8_inv_scale;
     int grid_cap;           // > 0: persistent grid of at most this many workgroups (each walks its tiles); 0: one workgroup per tile
     int stagger;            // > 0: the second-dispatched half of the grid starts this many 64-clock sleep units late (phase offset)
 };
