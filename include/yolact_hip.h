@@ -112,7 +112,8 @@ typedef struct yh_tuning {
                               * also fuse launches that only fill 64-pixel tiles (small batches: 3 % faster at batch 1-8), bits 8..
                               * the stagger in units of 4096 clocks. Default 17 (bits 0 and 4). Bits 1-3 are measured A/B forms, all
                               * slower than the default; bit 5 layer 1 only, bit 6 without the fused form of layer 1's FIRST block
-                              * (projection shortcut) */
+                              * (projection shortcut), bit 7 without layer 3's expand + next-reduce launch (bneck_xn_f16: used where
+                              * its 64-pixel tiles fill more than half a round of workgroups and at most one) */
 } yh_tuning;
 
 typedef struct yh_config {
