@@ -1,3 +1,9 @@
+"""In-kernel timeline of bneck_xn_f16: prints, per step, what each wave role spent in its phases - from
+s_memtime stamps of ONE workgroup. Needs a STAMPED build: the shipped kernel executes no stamp. To reproduce, put
+`if (blockIdx.x == 7 && (tid & 255) == 0) xn_stamps[(loader ? 128 : 0) + i] = __builtin_amdgcn_s_memtime();` (a __device__
+long long xn_stamps[256]) at the phase boundaries named in the print below and export
+`extern "C" int yh_debug_xn_stamps(long long* out)` (hipMemcpyFromSymbol); the output of the round-3 run is
+profiles/r03_xn_stamps.txt."""
 import ctypes, os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tiny-object-detection_amd"))
