@@ -82,3 +82,32 @@ def test_chain_layers_against_the_oracle(built, oracle):
         a, b = eng.tensor_frame(name, 1), net.get(name)[0]
         assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()))
     eng.close()
+
+
+def test_layer3_launch_in_fp8_precision_equals_separate_launches(built):
+    """configs[4]'s own share (YOLACT-700 R101, fp8 precision, 8 frames per GPU) is where layer 3's expand + next-reduce launch runs
+    (242 tiles on 256 CUs), and there its second output feeds an fp8 convolution: a' is written as E4M3 codes by the fused launch.
+    Same bytes as the separate launches on every head output and detection."""
+    import yolact_amd as ya
+    n, s = 8, 700
+    frames = np.random.default_rng(21).integers(0, 256, (n, s, s, 3), dtype=np.uint8)
+    engs, blob = [], None
+    for tune in ({}, {"chain": 17 + 128}):
+        e = ya.Engine(input_size=s, backbone=101, max_batch=n, use_graph=True, precision=ya.PRECISION_FP8, tune=tune or None)
+        if blob is None:
+            blob = e.generate_weights(seed=1)
+        e.load_weights(blob)
+        e.set_input(frames)
+        e.fp8_calibrate()
+        e.evaluate()
+        engs.append(e)
+    f, u = engs
+    names = [p["name"] for p in f.profile(with_tail=True, reps=1)]
+    assert sum(nm.startswith("bneck_xn") for nm in names) == 21, names          # l3b1 ... l3b21 (+ the next block's reduce conv each)
+    assert not any(nm.startswith("bneck_xn") for nm in (p["name"] for p in u.profile(with_tail=True, reps=1)))
+    for i in range(4):
+        assert np.array_equal(f.output(i), u.output(i)), i
+    for fr in range(n):
+        (da, ma), (db, mb) = f.detections(fr), u.detections(fr)
+        assert da == db and np.array_equal(ma, mb), fr
+    f.close(); u.close()
