@@ -992,7 +992,9 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     const int splitk_min = h->tune.splitk_minsteps, t64_mode = h->tune.t64, t64_min = h->tune.t64_minsteps;
     const bool ring128 = tile == TILE_128x128_S3 || tile == TILE_128x128_S4;
     const bool ring64 = (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && t64_mode >= 2;
-    if ((ring128 && p.ksteps >= splitk_min) || (ring64 && p.ksteps >= t64_min)) {
+    // (launches of at most 32 output pixels - P6 / P7 at batch 1: 25 and 9 - do not split: four workgroups walking 36 k-steps take
+    // as long as their slices plus the reduce launch, and the step has two launches fewer)
+    if (p.M > 32 && ((ring128 && p.ksteps >= splitk_min) || (ring64 && p.ksteps >= t64_min))) {
         // few tiles, long K: split K so that about one workgroup per CU streams the weights
         const int tm = conv_tile_m(tile);
         const long long tiles = (long long)((p.M + tm - 1) / tm) * p.n_ch_tiles;
