@@ -22,6 +22,9 @@ echo "[4/6] rocprofv3 kernel stats of the bench command"
 # (the batch-64 leg alone: the kernel averages of this CSV are then the headline step's own, as the bench line's roofline is)
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-batch1 --no-configs4 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp "$(find $OUT/stats -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats.csv
+# (configs[4]'s share under the profiler too: its layer-3 launches are the eight-wave bneck_xn_f16)
+rocprofv3 --kernel-trace --stats -d $OUT/stats4 -o run --output-format csv -- python3 $R/bench.py --backbone 101 --size 700 --precision fp8 --batch 8 --no-cpu-baseline --no-batch1 --no-configs4 > $OUT/bench4_under_rocprof.json 2> $OUT/stats4.log
+cp "$(find $OUT/stats4 -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_rocprofv3_kernel_stats_configs4.csv
 echo "[5/6] per-launch tables, the configs[4] lines, the reference-path timings"
 python3 $R/tools/profile_table.py --batch 64 > $OUT/${TAG}_hipevent_per_launch_batch64.txt
 python3 $R/tools/profile_table.py --batch 1 > $OUT/${TAG}_hipevent_per_launch_batch1.txt
@@ -42,5 +45,5 @@ echo "[6/6] SQ counters"
     python3 $R/tools/pmc_summary.py "$(find $OUT/pmc_$tag -name "*counter_collection.csv" | sort | tail -1)"
   done
 } > $OUT/${TAG}_pmc_kernels.txt
-rm -rf $OUT/stats $OUT/pmcF $OUT/pmcW; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
+rm -rf $OUT/stats $OUT/stats4 $OUT/pmcF $OUT/pmcW; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
 echo done
