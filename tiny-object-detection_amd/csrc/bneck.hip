@@ -381,10 +381,10 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
 //   a' = relu(W_a' y + bias_a')          1024 -> 256   (written: the next block's conv_b input; in fp8 precision also / only as E4M3)
 //
 // for one tile of 64 pixels per workgroup: two launches become one and y is not read back. What the workgroup moves most is
-// WEIGHTS - both panels, 1 MB, stream through LDS once per tile (64 KB per 64-channel chunk of y) - and what that costs is not L2
-// bandwidth (tools/exp/dma_probe.hip: 126 GB/s per CU) but ISSUE: an LDS-DMA instruction moves 1 KB and holds its wave for
-// 110-150 clocks here (in-kernel s_memtime stamps: 2 000-2 700 clocks per step for a wave's 18), during which that wave issues
-// nothing else. So the workgroup is EIGHT waves with two jobs:
+// WEIGHTS - both panels, 1 MB, stream through LDS once per tile (64 KB per 64-channel chunk of y). With four waves doing
+// everything that cost ISSUE time first: an LDS-DMA instruction moves 1 KB and held its wave for 110-150 clocks (in-kernel
+// s_memtime stamps: 2 000-2 700 clocks per step for a wave's 18), during which that wave issues nothing else. So the workgroup is
+// EIGHT waves with two jobs (52 -> 40 us per launch; what bounds it now is the L2 -> LDS path itself, ~25-30 B/clock/CU):
 //   waves 0-3 (compute)  GEMM 2: acc2[32 ch x 32 px] = W_c tile x b; + bias + residual, ReLU, f16, in place into the stage |M|
 //                        their half of GEMM 3                                                                               |E|
 //   waves 4-7 (loaders)  step oc + 1's residual rows and W_c tile by LDS-DMA |M| the y chunk's whole-row stores out of the stage,
