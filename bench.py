@@ -13,6 +13,7 @@ softmax/top-k/Fast-NMS/mask assembly), hipGraph-replayed. Frames shard across ra
 blob from rank 0. PyTorch is plumbing here (device buffers, torch.distributed), not the product.
 """
 import argparse
+import threading
 import json
 import os
 import sys
@@ -51,12 +52,16 @@ def all_ranks_ok(dist, ok, device):
     return bool(t.item())
 
 
-def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_library=True):
+LIBRARY_BROADCAST_DEADLINE_S = 120
+_LIBRARY_CALL_STUCK = False
+
+
+def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_library=True, device=None):
     """The path's ONE collective: rank 0's weights -> every rank's `src` engine. Preferred: the library's own RCCL
     broadcast (yh_rank_broadcast_weights: ncclCommInitRank + ncclBroadcast of the canonical blob over xGMI - the
     call a Rust host would make); if librccl cannot be opened on some rank, or the call fails on
     some rank, every rank falls back to torch.distributed.broadcast + yh_load_weights_device. Returns how it went."""
-    dev = f"cuda:{local_rank}"
+    dev = device or f"cuda:{local_rank}"
     blob_host = None
     if rank == 0:
         blob_host = src.generate_weights(seed)
@@ -73,19 +78,39 @@ def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_l
         if all_ranks_ok(dist, ident is not None, dev):
             box = [ident if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)   # the id travels by the host's own means (128 bytes)
-            ok = True
-            try:
-                src.rank_broadcast_weights(box[0], rank, world, 0)
-            except Exception as e:               # noqa: BLE001
-                ok, why = False, f"yh_rank_broadcast_weights failed on rank {rank}: {e}"
+            # The library's RCCL path has never run with more than one rank on hardware this project could reach (INTEGRATION.md
+            # §4), and a rank that fails inside ncclCommInitRank leaves its peers blocked there. A measurement must not hang on
+            # it: the call runs in a helper thread under a deadline; a rank that misses it reports so, every rank falls back to
+            # torch.distributed.broadcast, and the process leaves through os._exit at the end (the blocked call is never joined).
+            res = {}
+
+            def _call():
+                try:
+                    src.rank_broadcast_weights(box[0], rank, world, 0)
+                    res["ok"] = True
+                except Exception as e:           # noqa: BLE001
+                    res["err"] = str(e)
+            th = threading.Thread(target=_call, daemon=True)
+            th.start()
+            th.join(timeout=LIBRARY_BROADCAST_DEADLINE_S)
+            ok = bool(res.get("ok"))
+            if th.is_alive():
+                global _LIBRARY_CALL_STUCK
+                _LIBRARY_CALL_STUCK = True
+                why = f"yh_rank_broadcast_weights did not return within {LIBRARY_BROADCAST_DEADLINE_S} s on rank {rank}"
+            elif not ok:
+                why = f"yh_rank_broadcast_weights failed on rank {rank}: {res.get('err')}"
             if all_ranks_ok(dist, ok, dev):
                 return "yh_rank_broadcast_weights (library RCCL: ncclCommInitRank + ncclBroadcast)"
+            if not why:
+                why = "yh_rank_broadcast_weights failed or timed out on another rank"
     nbytes = src.weights_nbytes()
     blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if rank == 0:
         blob.copy_(torch.from_numpy(blob_host))
     broadcast_weights(dist, blob)
-    torch.cuda.synchronize()
+    if blob.is_cuda:
+        torch.cuda.synchronize()
     if rank != 0:
         src.load_weights_device(blob.data_ptr(), nbytes)
     return "torch.distributed.broadcast + yh_load_weights_device" + (f" (library path not taken: {why})" if why else "")
@@ -699,7 +724,9 @@ def main():
         # BASELINE.json configs[4]: YOLACT-700 ResNet-101, fp8 operands on the fp8 MFMA, batch 64 across 8 GPUs = 8 frames per
         # GPU - this rank's share, timed in the same run (same contract: resident frames, graph replay, max over ranks)
         src4 = ya.Engine(input_size=700, backbone=101, max_batch=1, use_graph=False, device=local_rank)
-        how4 = replicate_weights(ya, torch, dist, rank, world, local_rank, src4, a.seed, use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast))
+        # (the library's RCCL path again only if it worked for the headline engine's weights)
+        how4 = replicate_weights(ya, torch, dist, rank, world, local_rank, src4, a.seed,
+                                 use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast) and (world == 1 or how.startswith("yh_rank_broadcast_weights")))
         s4 = max(a.steps, 20)
         dt4, prof4, flops4, _, aux4 = run_config(ya, torch, dist, rank, world, local_rank, a.configs4_batch, s4, max(a.warmup, 3), a.seed, 700,
                                                   src4.weights_device_ptr(), src4.weights_nbytes(), backbone=101, precision="fp8", tune=tune)
@@ -749,6 +776,9 @@ def main():
         line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"], backbone=a.backbone,
                                             fp8_layers=aux.get("fp8_layers"), accept=aux.get("accept"))
     print(json.dumps(line), flush=True)
+    if _LIBRARY_CALL_STUCK:      # a helper thread is still inside the library's RCCL call: no teardown that could wait for it
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

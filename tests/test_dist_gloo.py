@@ -110,3 +110,68 @@ def test_measured_traffic_reads_the_committed_pmc_file():
     t, src = bench.measured_traffic("conv_igemm_f16<256,256,2,4,0,2,mfma16>", 64)
     assert src and src.startswith("profiles/") and t > 1e8
     assert bench.measured_traffic("no_such_kernel", 64) == (None, None)
+
+
+class _FakeEngine:
+    """Stands in for yolact_amd.Engine in bench.replicate_weights: rank 1's library broadcast never returns in time."""
+    def __init__(self, rank, nbytes, hang_s):
+        self.rank, self.nbytes, self.hang_s, self.loaded = rank, nbytes, hang_s, None
+
+    def generate_weights(self, seed):
+        return (np.arange(self.nbytes, dtype=np.int64) * 7 + seed).astype(np.uint8)
+
+    def load_weights(self, blob):
+        self.loaded = np.array(blob, copy=True)
+
+    def weights_nbytes(self):
+        return self.nbytes
+
+    def rank_broadcast_weights(self, ident, rank, world, root):
+        import time
+        if rank == 1:
+            time.sleep(self.hang_s)          # a peer blocked inside ncclCommInitRank
+        raise RuntimeError("no RCCL in this test")
+
+    def load_weights_device(self, ptr, n):
+        import ctypes
+        self.loaded = np.frombuffer((ctypes.c_uint8 * n).from_address(ptr), dtype=np.uint8).copy()
+
+
+class _FakeYa:
+    @staticmethod
+    def rccl_unique_id():
+        return b"\0" * 128
+
+
+def _worker_deadline(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bench.LIBRARY_BROADCAST_DEADLINE_S = 1
+        eng = _FakeEngine(rank, 4096, hang_s=20)
+        how = bench.replicate_weights(_FakeYa, torch, dist, rank, world, 0, eng, 3, use_library=True, device="cpu")
+        np.save(os.path.join(out_dir, f"w{rank}.npy"), eng.loaded)
+        with open(os.path.join(out_dir, f"how{rank}.txt"), "w") as f:
+            f.write(how + "\n" + str(bench._LIBRARY_CALL_STUCK))
+    finally:
+        dist.destroy_process_group()
+    os._exit(0)   # (rank 1's helper thread is still asleep in the fake library call: what bench.main does in that case)
+
+
+def test_library_broadcast_that_hangs_on_one_rank_falls_back_within_its_deadline(tmp_path):
+    """bench.replicate_weights runs the library's RCCL broadcast under a deadline: here rank 0's call fails at once and rank 1's
+    blocks (the hang mode INTEGRATION.md §4 describes); both ranks must agree on the torch.distributed fallback within seconds,
+    end up with rank 0's weights, and the blocked rank must know that it may not tear down normally."""
+    import time
+    t0 = time.time()
+    mp.spawn(_worker_deadline, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert time.time() - t0 < 15
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    assert np.array_equal(w0, w1) and w0[5] == (5 * 7 + 3) % 256
+    how0, how1 = (open(tmp_path / f"how{r}.txt").read().split("\n") for r in (0, 1))
+    assert how0[0].startswith("torch.distributed.broadcast") and how1[0].startswith("torch.distributed.broadcast")
+    assert "failed on rank 0" in how0[0] and "did not return within 1 s on rank 1" in how1[0]
+    assert how0[1] == "False" and how1[1] == "True"
