@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 2
+#define YH_ABI_VERSION 3
 
 enum {
     YH_OK = 0,
@@ -114,6 +114,11 @@ typedef struct yh_tuning {
                               * slower than the default; bit 5 layer 1 only, bit 6 without the fused form of layer 1's FIRST block
                               * (projection shortcut), bit 7 without layer 3's expand + next-reduce launch (bneck_xn_f16: used where
                               * its 64-pixel tiles fill more than half a round of workgroups and at most one) */
+    int32_t xn_tm;           /* layer 3's expand + next-reduce launch, pixel tile: -1 (default) 64-pixel tiles for about one round of
+                              * workgroups (bneck_xn_f16), else separate launches; 64 / 128: that form wherever the launch is eligible
+                              * (128: bneck_xn128_f16, bit-identical, measured no faster than the separate launches at batch 64) */
+    int32_t slabin;          /* a split-K convolution's partial slabs summed by the CONSUMER's loader instead of a reduce launch
+                              * (batch 1-2: 1, default); 0: splitk_reduce_f16 launches */
 } yh_tuning;
 
 typedef struct yh_config {

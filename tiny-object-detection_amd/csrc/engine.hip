@@ -129,7 +129,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, slabin;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -142,6 +142,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
+    r.xn_tm = t.xn_tm; r.slabin = d(t.slabin, 1);
     return r;
 }
 
@@ -1094,25 +1095,34 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
 // The no-3x3 form (bneck.hip: NOB): does the expand conv `oc` of a 256-plane identity block also run the next block's reduce conv
 // at batch n? One eight-wave workgroup per CU and 64-pixel tiles: for launches of about one tile per CU, where the two separate
 // launches are latency bound (YOLACT-700 R101 at 8 frames: 22 + 25 us -> one launch of 40). tune.chain bit 7 turns it off.
-bool xn_active(const yh_engine* h, const Op& oc, int n) {
-    if (!(h->tune.chain & 1) || (h->tune.chain & 128) || oc.xn_a < 0 || n < 1 || oc.kind != OP_CONV) return false;
+// Returns the launch's pixel tile: 0 (the two convolutions stay separate launches), 64 or 128.
+int xn_tile(const yh_engine* h, const Op& oc, int n) {
+    if (!(h->tune.chain & 1) || (h->tune.chain & 128) || oc.xn_a < 0 || n < 1 || oc.kind != OP_CONV) return 0;
     const Panel& pc = h->panels[oc.panel];
     const Op& oa = h->ops[oc.xn_a];
     const Panel& pa = h->panels[oa.panel];
     const long long pq = (long long)oc.P * oc.Q, M = (long long)n * pq;
-    // One round of tiles and at least half a round: measured per step, interleaved (tools/study/xn_ab_c4.py, tools/ab_tune.py):
-    // YOLACT-700 R101 fp8 at 8 frames (242 tiles) 3.242 -> 3.089 ms; YOLACT-550 R50 at batch 8 (154) 1.887 -> 1.876; but batch 4
-    // (77) 1.252 -> 1.272, batch 16 (307: two rounds) 3.076 -> 3.085, R101 at 12 frames (363) 4.572 -> 4.621. The launch is bound by
-    // the L2 -> LDS path (1 MB of weights per 64-pixel tile, ~40 us per round); the separate launches win once they fill the chip.
+    if (pc.k != 1 || pc.Kpad != 256 || pc.cout != 1024 || oc.stride != 1 || oc.dual || oc.res_up || !oc.has_res || oc.act != 1 || oc.nlev > 0) return 0;
+    if (oc.in.c != 256 || oc.in.img_stride != pq * 256 || oc.out.c != 1024 || oc.out.img_stride != pq * 1024 || oc.res.c != 1024 || oc.res.img_stride != pq * 1024) return 0;
+    if (pa.k != 1 || pa.Kpad != 1024 || pa.cout != 256 || oa.stride != 1 || oa.dual || oa.has_res || oa.act != 1 || oa.out.c != 256 || oa.out.img_stride != pq * 256) return 0;
+    if (oa.in.d != oc.out.d) return 0;
+    if (h->fp8_active && (oc.fp8 || oa.fp8 || oc.write_q || !oc.write_f16)) return 0;
+    const bool fits128 = (M + 128) * 2048 < 0xFFFFFFFFll;   // (the 128-pixel form stores y through a 32-bit buffer descriptor)
+    if (h->tune.xn_tm == 64 || (h->tune.xn_tm == 128 && fits128)) return h->tune.xn_tm;   // tests / A-B: this form wherever the launch is eligible
+    // 64-pixel tiles (eight waves, dedicated loader waves): one round of tiles and at least half a round - measured per step,
+    // interleaved (tools/study/xn_ab_c4.py, tools/ab_tune.py): YOLACT-700 R101 fp8 at 8 frames (242 tiles) 3.242 -> 3.089 ms;
+    // YOLACT-550 R50 at batch 8 (154) 1.887 -> 1.876; but batch 4 (77) 1.252 -> 1.272, batch 16 (307: two rounds) 3.076 -> 3.085, R101
+    // at 12 frames (363) 4.572 -> 4.621. That launch is bound by the L2 -> LDS path (1 MB of weights per 64-pixel tile, ~40 us per
+    // round); the separate launches win once they fill the chip.
     const long long tiles = (M + 63) / 64;
-    if (tiles > h->tune.plan_cus || 2 * tiles <= h->tune.plan_cus) return false;
-    if (pc.k != 1 || pc.Kpad != 256 || pc.cout != 1024 || oc.stride != 1 || oc.dual || oc.res_up || !oc.has_res || oc.act != 1 || oc.nlev > 0) return false;
-    if (oc.in.c != 256 || oc.in.img_stride != pq * 256 || oc.out.c != 1024 || oc.out.img_stride != pq * 1024 || oc.res.c != 1024 || oc.res.img_stride != pq * 1024) return false;
-    if (pa.k != 1 || pa.Kpad != 1024 || pa.cout != 256 || oa.stride != 1 || oa.dual || oa.has_res || oa.act != 1 || oa.out.c != 256 || oa.out.img_stride != pq * 256) return false;
-    if (oa.in.d != oc.out.d) return false;
-    if (h->fp8_active && (oc.fp8 || oa.fp8 || oc.write_q || !oc.write_f16)) return false;
-    return true;
+    if (tiles <= h->tune.plan_cus && 2 * tiles > h->tune.plan_cus) return 64;
+    // 128-pixel tiles (bneck_xn128_f16, round 4: half the weight traffic per pixel) are NOT part of the default plan: at batch 64
+    // (613 tiles, 2.4 rounds) the launch measures 157-163 us against 162 for the two launches it replaces - with every memory
+    // stream dropped it still takes 132 us (tools/study/xn128_ablate.py): it is bound by its two barriers per 64-channel chunk,
+    // not by bytes. tune.xn_tm = 128 selects it (bit-identical, tests/test_gpu_bneck.py).
+    return 0;
 }
+bool xn_active(const yh_engine* h, const Op& oc, int n) { return xn_tile(h, oc, n) != 0; }
 int fill_xn_params(yh_engine* h, const Op& oc, int n, BneckParams* out) {
     const Op& oa = h->ops[oc.xn_a];
     const Panel &pc = h->panels[oc.panel], &pa = h->panels[oa.panel];
@@ -1131,6 +1141,7 @@ int fill_xn_params(yh_engine* h, const Op& oc, int n, BneckParams* out) {
     p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias;
     p.a_next = (!h->fp8_active || oa.write_f16) ? oa.out.d : nullptr;
     if (h->fp8_active && oa.write_q) { p.a_next8 = oa.out.q; p.a_next8_inv_scale = 1.0f / h->act_scale[oa.out.sid]; }
+    p.stagger = h->tune.ablate >> 4;   // timing only (bneck_xn128_f16): bits 4-7 of tune.ablate drop the residual / y-store / W_c / W_a' stream
     *out = p;
     return YH_OK;
 }
@@ -1144,7 +1155,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
         BneckParams bp;
         const int rc = fill_xn_params(h, o, n, &bp);
         if (rc) return rc;
-        e = launch_bneck(bp, 256, 64, side ? h->side : h->stream);
+        e = launch_bneck(bp, 256, xn_tile(h, o, n), side ? h->side : h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, "bneck_chain_f16 (no 3x3):" + o.name + ": " + hipGetErrorString(e));
         return YH_OK;
     }
@@ -1486,7 +1497,7 @@ int ensure_out_f32(yh_engine* h, size_t nfloats) {
 // ================================================================================================
 extern "C" {
 
-const char* yh_version(void) { return "yolact-hip 0.2.0 (gfx950, MFMA f16 / fp8 implicit-GEMM; ABI 2)"; }
+const char* yh_version(void) { return "yolact-hip 0.4.0 (gfx950, MFMA f16 / fp8 implicit-GEMM; ABI 3)"; }
 
 void yh_default_config(yh_config* cfg) {
     memset(cfg, 0, sizeof *cfg);
@@ -1636,6 +1647,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
+    out->xn_tm = t.xn_tm; out->slabin = t.slabin;
     return YH_OK;
 }
 
@@ -2454,7 +2466,7 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 // expand conv + next reduce conv: both convolutions' FLOPs; HBM bytes = b + residual in, y + a' out, the weights
                 const Op& oa = h->ops[o.xn_a];
                 const double px = (double)n * o.P * o.Q;
-                h->prof_labels[i] = std::string(bneck_symbol(256, 64, true, false)) + ":" + o.name + "+" + oa.name;
+                h->prof_labels[i] = std::string(bneck_symbol(256, xn_tile(h, o, n), true, false)) + ":" + o.name + "+" + oa.name;
                 fl += oa.flops_per_img * n;
                 by = 2.0 * px * (256.0 + 1024.0 + 1024.0) + px * 256.0 * ((oa.write_f16 || !h->fp8_active ? 2.0 : 0.0) + (h->fp8_active && oa.write_q ? 1.0 : 0.0)) + o.bytes_fixed + oa.bytes_fixed;
             } else if (o.kind == OP_CONV && chain_active(h, o, n)) {
