@@ -53,22 +53,35 @@ def all_ranks_ok(dist, ok, device):
 
 
 LIBRARY_BROADCAST_DEADLINE_S = 120
-_LIBRARY_CALL_STUCK = False
+_LIBRARY_CALL_STUCK = False   # on THIS rank a helper thread is still inside yh_rank_broadcast_weights: leave through os._exit
 
 
-def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_library=True, device=None):
-    """The path's ONE collective: rank 0's weights -> every rank's `src` engine. Preferred: the library's own RCCL
+def leave_if_stuck():
+    """A rank whose helper thread is still blocked inside the library's RCCL call must not run any teardown that could wait for
+    it (interpreter exit joins nothing, but HIP / RCCL teardown with a thread inside ncclCommInitRank is the hang the deadline
+    exists to avoid): flush and leave. Called by EVERY rank right after its last collective."""
+    if _LIBRARY_CALL_STUCK:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+
+
+def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_library=True, device=None, make_engine=None):
+    """The path's ONE collective: rank 0's weights -> every rank's weight-holding engine. Preferred: the library's own RCCL
     broadcast (yh_rank_broadcast_weights: ncclCommInitRank + ncclBroadcast of the canonical blob over xGMI - the
     call a Rust host would make); if librccl cannot be opened on some rank, or the call fails on
-    some rank, every rank falls back to torch.distributed.broadcast + yh_load_weights_device. Returns how it went."""
+    some rank, every rank falls back to torch.distributed.broadcast + yh_load_weights_device. Returns (how it went, the
+    engine that holds the weights): that is `src`, unless this rank's library call is STUCK - then `src` is never touched
+    again (the blocked thread still owns it: no load, no close - the handle is leaked on purpose) and the fallback loads
+    into a fresh engine from make_engine()."""
     dev = device or f"cuda:{local_rank}"
     blob_host = None
     if rank == 0:
         blob_host = src.generate_weights(seed)
         src.load_weights(blob_host)
     if world == 1:
-        return "single GPU (no collective)"
+        return "single GPU (no collective)", src
     why = ""
+    stuck_here = False
     if use_library:
         ident = None
         try:
@@ -96,14 +109,21 @@ def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_l
             ok = bool(res.get("ok"))
             if th.is_alive():
                 global _LIBRARY_CALL_STUCK
-                _LIBRARY_CALL_STUCK = True
+                _LIBRARY_CALL_STUCK = stuck_here = True
                 why = f"yh_rank_broadcast_weights did not return within {LIBRARY_BROADCAST_DEADLINE_S} s on rank {rank}"
             elif not ok:
                 why = f"yh_rank_broadcast_weights failed on rank {rank}: {res.get('err')}"
             if all_ranks_ok(dist, ok, dev):
-                return "yh_rank_broadcast_weights (library RCCL: ncclCommInitRank + ncclBroadcast)"
+                return "yh_rank_broadcast_weights (library RCCL: ncclCommInitRank + ncclBroadcast)", src
             if not why:
                 why = "yh_rank_broadcast_weights failed or timed out on another rank"
+    if stuck_here:
+        # the blocked thread may write into `src` whenever its peers' sockets close: a fresh handle takes the weights
+        if make_engine is None:
+            raise RuntimeError("the library's RCCL call is stuck on this rank and no engine factory was given")
+        src = make_engine()
+        if rank == 0:
+            src.load_weights(blob_host)
     nbytes = src.weights_nbytes()
     blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if rank == 0:
@@ -113,7 +133,7 @@ def replicate_weights(ya, torch, dist, rank, world, local_rank, src, seed, use_l
         torch.cuda.synchronize()
     if rank != 0:
         src.load_weights_device(blob.data_ptr(), nbytes)
-    return "torch.distributed.broadcast + yh_load_weights_device" + (f" (library path not taken: {why})" if why else "")
+    return "torch.distributed.broadcast + yh_load_weights_device" + (f" (library path not taken: {why})" if why else ""), src
 
 
 def max_over_ranks(dist, seconds, device):
@@ -126,13 +146,27 @@ def max_over_ranks(dist, seconds, device):
     return float(t.item())
 
 
-def dominant_kernel(prof):
-    """Groups per-launch hipEvent timings by kernel symbol; returns the symbol with most time."""
+def kernel_family(sym):
+    """Tile family of a kernel symbol: `conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]` -> `conv_igemm_f16<256,256,2,4,0,2>` - the
+    bracket suffixes ([ml] multi-level, [+1x1] fused tail, [3x3] the streaming tile's 3x3 form) and the flag arguments (mfma16 ...)
+    name template flags of ONE tile (conv_igemm.hip), which rocprofv3 lists as symbols of their own; a roofline chosen by symbol
+    string split the 256 x 256 tile three ways and never reported the step's largest family."""
+    base = sym.split("[")[0]
+    if base.startswith("conv_igemm_f16<") and base.endswith(">"):
+        args = base[len("conv_igemm_f16<"):-1].split(",")
+        return "conv_igemm_f16<" + ",".join(args[:6]) + ">"
+    return base
+
+
+def dominant_kernel(prof, key=None):
+    """Groups per-launch hipEvent timings by kernel symbol (key = kernel_family: by tile family); returns the group with most time."""
     by = {}
     for p in prof:
         sym = p["name"].split(":")[0]
-        d = by.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        k = key(sym) if key else sym
+        d = by.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, symbols={}))
         d["ms"] += p["ms"]; d["flops"] += p["flops"]; d["bytes"] += p["bytes"]; d["launches"] += 1
+        d["symbols"][sym] = d["symbols"].get(sym, 0) + 1
     sym = max(by, key=lambda k: by[k]["ms"])
     return sym, by
 
@@ -149,14 +183,17 @@ def measured_traffic(sym, batch):
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        k = t.get("kernels", {}).get(sym)
-        if k and t.get("batch") == batch:
-            return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        ks = t.get("kernels", {})
+        syms = sym if isinstance(sym, dict) else {sym: 1}      # a family: {symbol: launches per step}
+        if t.get("batch") == batch and all(k in ks for k in syms):
+            n = sum(syms.values())
+            return round(sum(ks[k]["hbm_bytes_per_launch"] * c for k, c in syms.items()) / n), os.path.relpath(path, ROOT)
     return None, None
 
 
 def roofline_of(prof, batch=None):
-    sym, by = dominant_kernel(prof)
+    """The step's dominant TILE FAMILY (kernel_family) with the roofline that binds it."""
+    sym, by = dominant_kernel(prof, key=kernel_family)
     d = by[sym]
     total_ms = sum(p["ms"] for p in prof)
     # the roofline that binds this kernel: the larger of its MFMA and HBM fractions (a 1x1 conv on MFMA instructions is
@@ -168,11 +205,11 @@ def roofline_of(prof, batch=None):
         r = dict(bound="mfma", achieved=round(tf, 2), peak=mfma_peak, unit="TFLOP/s", frac=round(tf / mfma_peak, 4), traffic=None)
     else:
         r = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
-    r.update(kernel=sym, launches=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 5),
+    r.update(kernel=sym, symbols=d["symbols"], launches=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 5),
              share_of_step=round(d["ms"] / total_ms, 3), algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
              algorithmic_gbytes_hbm=round(d["bytes"] / 1e9, 4),
              hbm_gbs_algorithmic=round(gbs, 1), mfma_tflops=round(tf, 2))
-    traffic, src = measured_traffic(sym, batch)
+    traffic, src = measured_traffic(d["symbols"], batch)
     if traffic is not None:
         r["traffic"] = traffic
         r["traffic_unit"] = "HBM-side bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, KiB->B), vs algorithmic %d" % round(d["bytes"] / d["launches"])
@@ -469,28 +506,51 @@ def cpu_baseline(seed, frames_u8, budget_s=12.0, max_frames=64, eng_out=None, ba
     return r
 
 
-def fp8_vs_oracles(seed, frame_u8, eng_out, fp8_layers, backbone, nthreads):
-    """configs[4]: the fp8 engine's detections on one frame against (a) the oracle's fp8 forward mode with the engine's own
+def pool_accuracy(per_frame):
+    """Pools accuracy_vs_oracle records of several frames: counts add; the IoU figures are pooled over pixels the way one frame's
+    are over classes (a frame's union-of-masks intersection and union cannot be recovered from its ratio, so the pooled figure is
+    the detection-weighted mean of the frames' figures - stated as such)."""
+    out = dict(frames=len(per_frame))
+    for k in ("oracle_dets", "engine_dets", "matched_class_and_prior", "unmatched_oracle", "unmatched_engine"):
+        out[k] = sum(r[k] for r in per_frame)
+    for k in ("mask_iou_all", "mask_iou_matched"):
+        w = [(r[k], max(r["oracle_dets"], r["engine_dets"])) for r in per_frame if r.get(k) is not None]
+        out[k + "_mean"] = round(sum(v * n for v, n in w) / max(1, sum(n for _, n in w)), 5) if w else None
+        out[k + "_per_frame"] = [r.get(k) for r in per_frame]
+    out["matched_fraction_of_oracle"] = round(out["matched_class_and_prior"] / max(1, out["oracle_dets"]), 4)
+    return out
+
+
+def fp8_vs_oracles(seed, frames_u8, eng_outs, fp8_layers, backbone, nthreads):
+    """configs[4]: the fp8 engine's detections on its frames against (a) the oracle's fp8 forward mode with the engine's own
     calibrated scales - its checker - and (b) the f16 oracle - the price of the precision. The checker, never
-    the product."""
+    the product. frames_u8 [k][S][S][3], eng_outs = the engine's (detections, masks) of each: frame 0's figures as before, and
+    the figures pooled over all k frames (one noise frame's detection list is a handful of decisions near the threshold)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    net = O.Net(backbone, frame_u8.shape[1], 81, seed=seed)
+    net = O.Net(backbone, frames_u8.shape[1], 81, seed=seed)
     pri = net.priors()
-    out = {}
-    t0 = time.perf_counter()
-    h16 = net.forward(frame_u8[:1], f16=True, nthreads=nthreads)
-    out["oracle_f16_forward_s"] = round(time.perf_counter() - t0, 2)
-    out["engine_fp8_vs_oracle_f16"] = accuracy_vs_oracle(eng_out, O.detect(h16[0][0], h16[1][0], h16[2][0], h16[3][0], pri))
     lay = {}
     for name, sc in fp8_layers:
         for nm in ([f"{name}{l}" for l in range(5)] if name in ("head_t", "head_out") else [name]):
             lay[nm] = sc
-    net.set_fp8(lay)
-    h8 = net.forward(frame_u8[:1], f16=True, nthreads=nthreads)
-    net.set_fp8(None)
-    out["engine_vs_oracle_fp8_mode"] = accuracy_vs_oracle(eng_out, O.detect(h8[0][0], h8[1][0], h8[2][0], h8[3][0], pri))
+    out, a16, a8 = {}, [], []
+    for k in range(frames_u8.shape[0]):
+        t0 = time.perf_counter()
+        h16 = net.forward(frames_u8[k:k + 1], f16=True, nthreads=nthreads)
+        if k == 0:
+            out["oracle_f16_forward_s"] = round(time.perf_counter() - t0, 2)
+        a16.append(accuracy_vs_oracle(eng_outs[k], O.detect(h16[0][0], h16[1][0], h16[2][0], h16[3][0], pri)))
+        net.set_fp8(lay)
+        h8 = net.forward(frames_u8[k:k + 1], f16=True, nthreads=nthreads)
+        net.set_fp8(None)
+        a8.append(accuracy_vs_oracle(eng_outs[k], O.detect(h8[0][0], h8[1][0], h8[2][0], h8[3][0], pri)))
+    out["engine_fp8_vs_oracle_f16"] = a16[0]
+    out["engine_vs_oracle_fp8_mode"] = a8[0]
     out["engine_vs_oracle_fp8_mode"]["oracle_mode"] = f"fp8 forward mode, {len(fp8_layers)} E4M3 layers, the engine's calibrated scales"
+    if len(a16) > 1:
+        out["engine_fp8_vs_oracle_f16_all_frames"] = pool_accuracy(a16)
+        out["engine_vs_oracle_fp8_mode_all_frames"] = pool_accuracy(a8)
     return out
 
 
@@ -504,9 +564,44 @@ def family_rooflines(prof):
             continue
         tf, gbs = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9
         peak = MFMA_FP8_DENSE_PEAK_TFLOPS if sym.startswith("conv_igemm_fp8") else MFMA_F16_DENSE_PEAK_TFLOPS
-        out.append(dict(kernel=sym, launches=d["launches"], ms=round(d["ms"], 4), share_of_step=round(d["ms"] / total, 3),
+        out.append(dict(kernel=sym, family=kernel_family(sym), launches=d["launches"], ms=round(d["ms"], 4), share_of_step=round(d["ms"] / total, 3),
                         tflops=round(tf, 1), frac_mfma=round(tf / peak, 3), gbs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 3)))
     return out
+
+
+def tflite_record(ya, invokes=120):
+    """The reference's own model family (MobileNetV2-FPN YOLACT, uint8, 224 x 224: data/README.md:5-16) through the .tflite
+    executor (yh_tfl_*): the reference's literal workload - one 640 x 480 camera frame = two tiles, src/yolact.rs:192-234 - as
+    ms per classify(), plus launches per invoke and the share of CONV_2D launches on the int8 matrix pipes. The real
+    FRC_model.tflite is absent (.MISSING_LARGE_BLOBS); the model is the 136-op stand-in with the log's op census
+    (tests/tfl_models.mobilenetv2_yolact), serialised by tests/tfl_builder.py."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import tfl_builder as B
+        import tfl_models as M
+    except Exception as e:   # noqa: BLE001
+        return dict(error=f"model builder unavailable: {e}"[:200])
+    rng = np.random.default_rng(0)
+    model = M.mobilenetv2_yolact(rng)
+    eng = ya.TfliteEngine(bytes(B.serialize(model)))
+    frame = (rng.integers(0, 256, (480, 640, 3), dtype=np.uint32) * np.array([1 << 24, 1 << 16, 1 << 8], np.uint32)).sum(-1).astype(np.uint32).reshape(-1)
+    t = []
+    for _ in range(invokes):
+        f = frame.copy()
+        t0 = time.perf_counter(); eng.classify_frame(f, 640, 480, ya.COMPAT_SANE); t.append(time.perf_counter() - t0)
+    t = np.array(t[20:]) * 1e3
+    rec = dict(workload="classify(640x480 packed u32 frame) through a 136-op MobileNetV2-FPN-YOLACT uint8 .tflite stand-in: resize, two 224x224 tiles in one batch-2 pass, "
+                        "28x28 argmax post-process, x8 upsample, resize back - all on the device, host frame in and out (src/yolact.rs:192-234)",
+               ops=len(model.ops), ms_per_frame_median=round(float(np.median(t)), 4), ms_per_frame_p99=round(float(np.percentile(t, 99)), 4),
+               frames_per_s=round(1e3 / float(np.median(t)), 1), reference_published="~2 x 50 ms per frame on Pi 4 + Coral USB (data/README.md:12; out.log:429-430)")
+    try:
+        plan = eng.plan_summary()
+        rec.update(plan)
+    except Exception:   # noqa: BLE001 - older library without the summary call
+        pass
+    eng.close()
+    return rec
 
 
 VERBOSE = False
@@ -519,9 +614,9 @@ def progress(msg):
 
 
 def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, seed, size, blob_dev_ptr, blob_nbytes, ring=4, backbone=50,
-               precision="f16", tune=None):
+               precision="f16", tune=None, fp8_per_tensor=False):
     eng = ya.Engine(input_size=size, backbone=backbone, max_batch=batch, use_graph=True, device=local_rank,
-                    precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16, tune=tune)
+                    precision=ya.PRECISION_FP8 if precision == "fp8" else ya.PRECISION_F16, tune=tune, fp8_per_tensor=fp8_per_tensor)
     eng.load_weights_device(blob_dev_ptr, blob_nbytes)
     g = torch.Generator(device=f"cuda:{local_rank}")
     start, _ = shard_frames(world * batch, world, rank)
@@ -577,11 +672,14 @@ def run_config(ya, torch, dist, rank, world, local_rank, batch, steps, warmup, s
         progress(f"batch {batch}: final frame-0 detections")
         eng.set_input_device(bufs[0].data_ptr(), batch); eng.evaluate(); eng.sync()
         aux["dets_frame0"] = eng.detections(0, want_masks=True)
+        if batch <= 8:   # (configs[4]'s share: every frame's detections, for the pooled accuracy figures)
+            aux["host_frames"] = host
+            aux["dets_all"] = [aux["dets_frame0"]] + [eng.detections(f, want_masks=True) for f in range(1, batch)]
         acc_img = acceptance_frame(size)
         if acc_img is not None:
             eng.set_input(acc_img); eng.evaluate(); eng.sync()
             aux["accept"] = (acc_img, eng.detections(0, want_masks=True))
-        aux["fp8_layers"] = eng.fp8_layers() if precision == "fp8" else None
+        aux["fp8_layers"] = eng.fp8_channel_scales() if precision == "fp8" else None   # (name, one activation scale per input channel)
     if dist is not None:
         dist.barrier()
     eng.close()
@@ -662,6 +760,8 @@ def main():
     ap.add_argument("--no-batch1", action="store_true")
     ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] sub-record (YOLACT-700 R101 fp8 at this rank's share of 64 frames over 8 GPUs)")
     ap.add_argument("--configs4-batch", type=int, default=8, help="frames per GPU of the configs[4] sub-record (64 frames / 8 GPUs)")
+    ap.add_argument("--no-tflite", action="store_true", help="skip the tflite sub-record (the reference's own model family through the uint8 .tflite executor)")
+    ap.add_argument("--fp8-per-tensor", action="store_true", help="fp8 engines: one activation scale per tensor (round 3's scheme) instead of one per input channel - A/B of the accuracy figures")
     ap.add_argument("--verbose", action="store_true", help="phase markers on stderr")
     ap.add_argument("--tune", default="", help="comma-separated yh_tuning fields for A/B measurements, e.g. tailfork=1,k1tile=0 (default: none)")
     ap.add_argument("--torch-broadcast", action="store_true",
@@ -702,34 +802,39 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     # weights: generated once on rank 0, replicated with ONE RCCL broadcast over xGMI
-    src = ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=1, use_graph=False, device=local_rank)
-    nbytes = src.weights_nbytes()
-    how = replicate_weights(ya, torch, dist, rank, world, local_rank, src, a.seed, use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast))
+    make_src = lambda: ya.Engine(input_size=a.size, backbone=a.backbone, max_batch=1, use_graph=False, device=local_rank)   # noqa: E731
+    src0 = make_src()
+    nbytes = src0.weights_nbytes()
+    how, src = replicate_weights(ya, torch, dist, rank, world, local_rank, src0, a.seed, use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast),
+                                 make_engine=make_src)
+    # (src is src0 unless this rank's library call is stuck - then src0 is never touched again, not even closed: replicate_weights)
     blob_ptr = src.weights_device_ptr()
 
     dt, prof, flops, ndet, aux = run_config(ya, torch, dist, rank, world, local_rank, a.batch, a.steps, a.warmup,
-                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune)
+                                              a.seed, a.size, blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune, fp8_per_tensor=a.fp8_per_tensor)
     extra = {}
     if a.batch != 1 and not a.no_batch1:   # configs[1]: batch=1 latency case, same run
         s1 = max(a.steps * 4, 40)
         dt1, prof1, _, _, aux1 = run_config(ya, torch, dist, rank, world, local_rank, 1, s1, max(a.warmup, 5), a.seed, a.size,
-                                         blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune)
+                                         blob_ptr, nbytes, backbone=a.backbone, precision=a.precision, tune=tune, fp8_per_tensor=a.fp8_per_tensor)
         if rank == 0:
             extra["batch1"] = dict(workload=f"YOLACT-{a.size} R{a.backbone}-FPN batch=1 {a.precision} {a.size}x{a.size}x3 per GPU (configs[1])",
                                    value=round(world * s1 / dt1, 2), unit="frames/s", ms_per_step=round(dt1 / s1 * 1e3, 4),
                                    net_tflops=round(world * s1 / dt1 * flops / 1e12, 2), roofline=roofline_of(prof1, 1),
+                                   kernel_families=family_rooflines(prof1), launches_per_step=len(prof1),
                                    latency=aux1["latency"], pcie_inclusive_fps=aux1["pcie_inclusive_fps"], pcie_inclusive_fps_pageable=aux1["pcie_inclusive_fps_pageable"],
-                                   host_to_detections_latency=aux1.get("host_to_detections_latency"))
+                                   host_to_detections_latency=aux1.get("host_to_detections_latency"),
+                                   weights_replication=how + " (the headline record's blob: the batch-1 engine loads it device to device)")
     if a.batch != 1 and not a.no_configs4 and not (a.backbone == 101 and a.precision == "fp8"):
         # BASELINE.json configs[4]: YOLACT-700 ResNet-101, fp8 operands on the fp8 MFMA, batch 64 across 8 GPUs = 8 frames per
         # GPU - this rank's share, timed in the same run (same contract: resident frames, graph replay, max over ranks)
         src4 = ya.Engine(input_size=700, backbone=101, max_batch=1, use_graph=False, device=local_rank)
-        # (the library's RCCL path again only if it worked for the headline engine's weights)
-        how4 = replicate_weights(ya, torch, dist, rank, world, local_rank, src4, a.seed,
-                                 use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast) and (world == 1 or how.startswith("yh_rank_broadcast_weights")))
+        # (the library's RCCL path again only if it worked for the headline engine's weights: a stuck call is never repeated)
+        how4, src4 = replicate_weights(ya, torch, dist, rank, world, local_rank, src4, a.seed,
+                                       use_library=not (a.rehearse_on_one_gpu or a.torch_broadcast) and (world == 1 or how.startswith("yh_rank_broadcast_weights")))
         s4 = max(a.steps, 20)
         dt4, prof4, flops4, _, aux4 = run_config(ya, torch, dist, rank, world, local_rank, a.configs4_batch, s4, max(a.warmup, 3), a.seed, 700,
-                                                  src4.weights_device_ptr(), src4.weights_nbytes(), backbone=101, precision="fp8", tune=tune)
+                                                  src4.weights_device_ptr(), src4.weights_nbytes(), backbone=101, precision="fp8", tune=tune, fp8_per_tensor=a.fp8_per_tensor)
         src4.close()
         if rank == 0:
             fps4 = world * a.configs4_batch * s4 / dt4
@@ -744,11 +849,23 @@ def main():
                 ms = sum(k["ms"] for k in fp8f); fl = sum(k["tflops"] * k["ms"] for k in fp8f)
                 rec["fp8_launches"] = dict(launches=sum(k["launches"] for k in fp8f), ms=round(ms, 4), tflops=round(fl / ms, 1),
                                            peak=MFMA_FP8_DENSE_PEAK_TFLOPS, frac=round(fl / ms / MFMA_FP8_DENSE_PEAK_TFLOPS, 4))
+            rec["fp8_activation_scales"] = "one per tensor (yh_config.fp8_per_tensor = 1)" if a.fp8_per_tensor else "one per input channel, folded into the weights' K axis (round 4)"
             if world == 1 and not a.no_cpu_baseline:
-                rec["accuracy"] = fp8_vs_oracles(a.seed, aux4["host_frame"], aux4["dets_frame0"], aux4["fp8_layers"], 101, usable_cores())
+                if "dets_all" in aux4:
+                    rec["accuracy"] = fp8_vs_oracles(a.seed, aux4["host_frames"], aux4["dets_all"], aux4["fp8_layers"], 101, usable_cores())
+                else:
+                    rec["accuracy"] = fp8_vs_oracles(a.seed, aux4["host_frame"], [aux4["dets_frame0"]], aux4["fp8_layers"], 101, usable_cores())
+                if aux4.get("accept") is not None:   # ... and on the reference's own test image at 700 x 700
+                    img, dets = aux4["accept"]
+                    rec["accuracy_frc_balls"] = fp8_vs_oracles(a.seed, img, [dets], aux4["fp8_layers"], 101, usable_cores())
+                    rec["accuracy_frc_balls"]["frame"] = "tests/golden/frc_balls.png resized to 700x700 (bilinear)"
             extra["configs4"] = rec
-    src.close()
+    if world == 1 and rank == 0 and not a.no_tflite:
+        extra["tflite"] = tflite_record(ya)
+    if not _LIBRARY_CALL_STUCK:
+        src.close()
     if rank != 0:
+        leave_if_stuck()          # (every stuck rank, not only rank 0: right after its last collective)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -766,6 +883,8 @@ def main():
         "net_tflops": round(fps * flops / 1e12, 2), "gflop_per_frame": round(flops / 1e9, 2),
         "net_frac_of_mfma_peak": round(fps * flops / 1e12 / (MFMA_F16_DENSE_PEAK_TFLOPS * world), 4),   # against the f16 peak in either precision (mixed-precision step)
         "roofline": roofline_of(prof, a.batch),
+        "kernel_families": family_rooflines(prof),
+        "launches_per_step": len(prof),
         "latency": aux["latency"],
         "pcie_inclusive_fps": aux["pcie_inclusive_fps"],
         "pcie_inclusive_fps_pageable": aux["pcie_inclusive_fps_pageable"],
@@ -776,9 +895,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(a.seed, aux["host_frame"], budget_s=a.cpu_budget, eng_out=aux["dets_frame0"], backbone=a.backbone,
                                             fp8_layers=aux.get("fp8_layers"), accept=aux.get("accept"))
     print(json.dumps(line), flush=True)
-    if _LIBRARY_CALL_STUCK:      # a helper thread is still inside the library's RCCL call: no teardown that could wait for it
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+    leave_if_stuck()             # a helper thread is still inside the library's RCCL call: no teardown that could wait for it
     if dist is not None:
         dist.destroy_process_group()
 

@@ -139,7 +139,10 @@ typedef struct yh_config {
     int32_t fp8_f16_layers;/* YH_PRECISION_FP8 only: groups of the K-heavy 3x3 layers that stay f16 (a hybrid: accuracy for speed, DESIGN.md
                             * §10 table): bit 0 the shared head trunk, bit 1 the protonet (proto0..3), bit 2 the FPN's pred / down convs
                             * (p3..p7), bit 3 the backbone (layers 3-4). 0 (default): all 36 of YOLACT-700 R101 run fp8 */
-    int32_t reserved[5];   /* zero */
+    int32_t fp8_per_tensor;/* YH_PRECISION_FP8 only: 0 (default) yh_fp8_calibrate sets one activation scale per INPUT CHANNEL of every E4M3
+                            * tensor (folded into the consuming conv's weights along K, applied by the producer's epilogue as a vector:
+                            * no extra pass); 1: one scale per tensor (round 3's scheme) */
+    int32_t reserved[4];   /* zero */
     yh_tuning tune;        /* yh_default_config sets every field to -1 */
 } yh_config;
 
@@ -201,22 +204,30 @@ int yh_load_weights_host(yh_engine* h, const void* blob_host, size_t nbytes);
 int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
 
 /* ---- fp8 precision (yh_config.precision = YH_PRECISION_FP8; BASELINE.json configs[4]) -------------------------
- * The K-heavy 3x3 convolutions read OCP E4M3 operands on the block-scaled fp8 MFMA: weights with one scale per
- * output channel (fixed when the weights are loaded), activations with one scale per tensor, which must be set
- * before the first invoke - by calibration on representative frames, or layer by layer from stored values. */
-/* Runs the f16 forward of the frames last set and sets every fp8 input tensor's scale to max|x| / 448. YH_ESTATE (and
- * no scale changed) if that forward overflowed: a non-finite maximum would make every code of the tensor 0. */
+ * The K-heavy 3x3 convolutions read OCP E4M3 operands on the block-scaled fp8 MFMA. Activations: one scale per INPUT
+ * CHANNEL of every tensor such a convolution reads (round 4; yh_config.fp8_per_tensor = 1: one per tensor), which must be
+ * set before the first invoke - by calibration on representative frames, or layer by layer from stored values. The channel
+ * scale s[c] is folded into the consumer's weights along K (t = w * s[c]) before their quantisation with one scale per
+ * output channel (s_w = max |t| / 448), so the weights' E4M3 codes are (re)made whenever a tensor's scales are set; the
+ * producer's epilogue multiplies by 1 / s[c] - a vector instead of a scalar, no extra pass. */
+/* Runs the f16 forward of the frames last set and sets the scales of every fp8 input tensor to max|x[.., c]| / 448. YH_ESTATE
+ * (and no scale changed) if that forward overflowed: a non-finite maximum would make every code of the tensor 0. */
 int yh_fp8_calibrate(yh_engine* h);
 /* The convolutions that read E4M3 operands, in execution order: layer name (DESIGN.md layer names: "l3b0_b", "p5",
- * "proto0", "head_t" ...) and the activation scale of its input tensor. */
+ * "proto0", "head_t" ...) and the LARGEST channel scale of its input tensor (yh_fp8_layer_channel_scales gives them all). */
 int yh_fp8_layer_count(const yh_engine* h);
 int yh_fp8_layer_info(const yh_engine* h, int32_t i, const char** conv_name, float* act_scale);
+/* Channels of layer i's input tensor / its channel scales (n must equal the channel count; 1.0 where none is set yet). */
+int yh_fp8_layer_channels(const yh_engine* h, int32_t i);
+int yh_fp8_layer_channel_scales(const yh_engine* h, int32_t i, float* scales, int32_t n);
 /* Scales belong to TENSORS (allocations), not to layers: layers that read one allocation share theirs - P3..P7 live in one
- * pyramid buffer, so setting the scale of "p6" also sets it for "p7", "head_t" and "proto0" (yh_fp8_layer_info shows it).
- * A positive finite value is required. yh_invoke / yh_evaluate return YH_ESTATE, naming the layers, until EVERY E4M3
- * input tensor has a scale (by calibration or by this call). Loading weights AGAIN on a handle discards the scales (they
- * were calibrated for the old weights); scales set before the first load are kept. */
+ * pyramid buffer, so setting the scales of "p6" also sets them for "p7", "head_t" and "proto0" (yh_fp8_layer_info shows it).
+ * Positive finite values are required. yh_invoke / yh_evaluate return YH_ESTATE, naming the layers, until EVERY E4M3
+ * input tensor has its scales (by calibration or by these calls). Loading weights AGAIN on a handle discards the scales (they
+ * were calibrated for the old weights); scales set before the first load are kept. yh_fp8_set_layer_scale sets the same
+ * value in every channel (a per-tensor scale). */
 int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale);
+int yh_fp8_set_layer_channel_scales(yh_engine* h, int32_t i, const float* scales, int32_t n);
 
 /* ---- multi-GPU: the path's one collective (north_star: "weights replicated once via RCCL
  * broadcast over xGMI, no per-step collectives"). The reference's caller is a Rust process (src/main.rs:63-75,

@@ -103,9 +103,10 @@ void orc_net_set_fp8_study(orc_net* net, int on);
  * per input channel; w_mode 1 one scale per output channel | 2 E8M0 blocks of 32 along K; skip_csv: name prefixes kept f16.
  * Applies to the convolutions the engine's fp8 plan takes (3x3, cin >= 256 and % 128 == 0, cout % 256 == 0). */
 void orc_net_set_fp8_study_ex(orc_net* net, int act_mode, int w_mode, const char* skip_csv);
-/* fp8 forward mode (configs[4]): name the convolutions that read E4M3 operands, each with its activation scale */
+/* fp8 forward mode (configs[4]): name the convolutions that read E4M3 operands, each with its activation scales - one per
+ * INPUT CHANNEL, folded into the weights' K axis before their per-output-channel quantisation (orc_net.c: run_conv) */
 void orc_net_clear_fp8(orc_net* net);
-int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale);
+int orc_net_add_fp8_layer_ch(orc_net* net, const char* conv_name, const float* scales, int channels);
 float orc_e4m3_to_f32(uint8_t b);
 uint8_t orc_e4m3_from_f32(float x);              /* round to nearest even, saturating at +-448, NaN -> 0x7F */
 void orc_quantize_e4m3(const float* x, long long n, float inv_scale, uint8_t* y);

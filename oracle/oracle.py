@@ -213,15 +213,17 @@ class Net:
         return lib().orc_net_flops_per_frame(self.h)
 
     def set_fp8(self, layers=None):
-        """fp8 forward mode (configs[4]): `layers` = {conv name: activation scale} of the convolutions that read E4M3
-        operands (names as in orc_net.c: l3b0_b, p5, proto0, head_t0 ...); None / {} switches it off."""
+        """fp8 forward mode (configs[4]): `layers` = {conv name: activation scales} of the convolutions that read E4M3
+        operands (names as in orc_net.c: l3b0_b, p5, proto0, head_t0 ...) - one scale per INPUT CHANNEL (an array), or a
+        single number for the same scale in every channel; None / {} switches it off."""
         L = lib()
         L.orc_net_clear_fp8.argtypes = [C.c_void_p]
-        L.orc_net_add_fp8_layer.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
-        L.orc_net_add_fp8_layer.restype = C.c_int
+        L.orc_net_add_fp8_layer_ch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]
+        L.orc_net_add_fp8_layer_ch.restype = C.c_int
         L.orc_net_clear_fp8(self.h)
         for name, scale in (layers or {}).items():
-            assert L.orc_net_add_fp8_layer(self.h, name.encode(), float(scale)) == 0, name
+            v = np.ascontiguousarray(np.atleast_1d(np.asarray(scale, np.float32)))
+            assert L.orc_net_add_fp8_layer_ch(self.h, name.encode(), v.ctypes.data_as(C.POINTER(C.c_float)), int(v.size)) == 0, name
 
     def set_fp8_study_ex(self, act_mode=0, w_mode=1, skip=""):
         """Extended accuracy study (DESIGN.md §10): act_mode 0 off, 1 per tensor, 2 E8M0 blocks of 32, 3 per input channel;

@@ -81,7 +81,7 @@ struct orc_net {
     /* fp8 forward mode (DESIGN.md §Precision, configs[4]): the named convolutions read E4M3 operands - activations with
      * the GIVEN per-tensor scale (the engine's calibration result), weights with one scale per output channel */
     int n_fp8;
-    struct { char name[24]; float act_scale; } fp8_layers[256];
+    struct { char name[24]; float* sc; int c; } fp8_layers[256];   /* one activation scale per INPUT CHANNEL (a per-tensor scale: all equal) */
 };
 
 /* ------------------------------------------------------------------ canonical conv table */
@@ -340,29 +340,40 @@ static tensor* run_conv(orc_net* net, int* ci, const char* name, const tensor* x
     if (cw->cin != x->c) { fprintf(stderr, "oracle: conv %s cin %d vs %d\n", name, cw->cin, x->c); abort(); }
     int ho = out_dim(x->h, cw->kh, stride, pad), wo = out_dim(x->w, cw->kw, stride, pad);
     tensor* y = new_t(net, name, x->n, ho, wo, cw->cout);
-    /* fp8 forward mode: this convolution was named with its activation scale s_x.
-     *   x8 = e4m3(x * (1 / s_x))   on the stored (f16-rounded) input tensor, round to nearest even, saturating
-     *   w8 = e4m3(w * (1 / s_w[o])), s_w[o] = max_k |w[o][k]| / 448 (1 if the row is all zero)
-     *   y  = act(fma(sum x8 * w8, s_x * s_w[o], bias[o]) + residual), rounded to f16
+    /* fp8 forward mode: this convolution was named with its activation scales s[c], one per input channel (round 4; a
+     * per-tensor scale is the same value in every channel). The channel scale is folded into the WEIGHTS' K axis, so the
+     * kernel is the per-tensor one and the producer's epilogue multiplies by a vector instead of a scalar:
+     *   x8[p][c] = e4m3(x[p][c] * (1 / s[c]))   on the stored (f16-rounded) input tensor, round to nearest even, saturating
+     *   t[o][k]  = w[o][k] * s[c(k)]             (one f32 multiplication)
+     *   w8[o][k] = e4m3(t[o][k] * (1 / s_w[o])), s_w[o] = max_k |t[o][k]| / 448 (1 if the row is all zero)
+     *   y  = act(fma(sum x8 * w8, s_w[o], bias[o]) + residual), rounded to f16
      * the sum of products in f32 (products of two E4M3 values are exact in f32). */
     for (int li = 0; li < net->n_fp8; ++li)
         if (strcmp(net->fp8_layers[li].name, name) == 0) {
-            const float sx = net->fp8_layers[li].act_scale, inv_sx = 1.0f / sx;
-            size_t nx = (size_t)x->n * x->h * x->w * x->c, K = (size_t)cw->kh * cw->kw * cw->cin;
+            float* sc = (float*)malloc((size_t)x->c * sizeof(float));   /* (a single scale given: the same in every channel) */
+            if (net->fp8_layers[li].c != x->c && net->fp8_layers[li].c != 1) { fprintf(stderr, "oracle: fp8 layer %s: %d channel scales for %d channels\n", name, net->fp8_layers[li].c, x->c); abort(); }
+            for (int c = 0; c < x->c; ++c) sc[c] = net->fp8_layers[li].sc[net->fp8_layers[li].c == 1 ? 0 : c];
+            size_t nx = (size_t)x->n * x->h * x->w * x->c, K = (size_t)cw->kh * cw->kw * cw->cin, npx = nx / x->c;
             float* xq = (float*)malloc(nx * sizeof(float));
             float* wq = (float*)malloc(K * cw->cout * sizeof(float));
             float* chs = (float*)malloc((size_t)cw->cout * sizeof(float));
-            for (size_t i = 0; i < nx; ++i) xq[i] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i] * inv_sx));
+            float* inv = (float*)malloc((size_t)x->c * sizeof(float));
+            for (int c = 0; c < x->c; ++c) inv[c] = 1.0f / sc[c];
+            for (size_t i = 0; i < npx; ++i)
+                for (int c = 0; c < x->c; ++c) xq[i * x->c + c] = orc_e4m3_to_f32(orc_e4m3_from_f32(x->d[i * x->c + c] * inv[c]));
             for (int o = 0; o < cw->cout; ++o) {
                 float aw = 0.0f;
-                for (size_t k = 0; k < K; ++k) { float a = fabsf(cw->wt[k * cw->cout + o]); if (a > aw) aw = a; }
+                for (size_t k = 0; k < K; ++k) { float a = fabsf(cw->wt[k * cw->cout + o] * sc[k % x->c]); if (a > aw) aw = a; }
                 const float sw = aw > 0.0f ? aw / 448.0f : 1.0f, inv_sw = 1.0f / sw;
-                for (size_t k = 0; k < K; ++k) wq[k * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(cw->wt[k * cw->cout + o] * inv_sw));
-                chs[o] = sx * sw;
+                for (size_t k = 0; k < K; ++k) {
+                    const float t = cw->wt[k * cw->cout + o] * sc[k % x->c];
+                    wq[k * cw->cout + o] = orc_e4m3_to_f32(orc_e4m3_from_f32(t * inv_sw));
+                }
+                chs[o] = sw;
             }
             conv_core(xq, x->n, x->h, x->w, x->c, wq, cw->bias, cw->cout, cw->kh, cw->kw, stride, pad,
                       res ? res->d : NULL, act, net->f16, net->nthreads, y->d, ho, wo, chs);
-            free(xq); free(wq); free(chs);
+            free(xq); free(wq); free(chs); free(inv); free(sc);
             return y;
         }
     /* extended study (orc_net_set_fp8_study_ex): activations 1 per tensor | 2 MX blocks of 32 channels (E8M0) | 3 one scale
@@ -543,6 +554,7 @@ orc_net* orc_net_create(const orc_net_cfg* cfg, const void* blob, size_t nbytes)
 void orc_net_destroy(orc_net* net) {
     if (!net) return;
     clear_t(net);
+    orc_net_clear_fp8(net);
     for (int i = 0; i < net->nconv; ++i) { free(net->convs[i].wt); free(net->convs[i].bias); }
     free(net->convs);
     free(net->priors);
@@ -554,11 +566,18 @@ void orc_net_set_fp8_study_ex(orc_net* net, int act_mode, int w_mode, const char
     net->fp8_act_mode = act_mode; net->fp8_w_mode = w_mode;
     snprintf(net->fp8_skip, sizeof net->fp8_skip, "%s", skip_csv ? skip_csv : "");
 }
-void orc_net_clear_fp8(orc_net* net) { net->n_fp8 = 0; }
-int orc_net_add_fp8_layer(orc_net* net, const char* conv_name, float act_scale) {
-    if (net->n_fp8 >= 256 || !(act_scale > 0.0f)) return -1;
+void orc_net_clear_fp8(orc_net* net) {
+    for (int i = 0; i < net->n_fp8; ++i) free(net->fp8_layers[i].sc);
+    net->n_fp8 = 0;
+}
+int orc_net_add_fp8_layer_ch(orc_net* net, const char* conv_name, const float* scales, int channels) {
+    if (net->n_fp8 >= 256 || channels < 1) return -1;
+    for (int c = 0; c < channels; ++c) if (!(scales[c] > 0.0f)) return -1;
+    float* sc = (float*)malloc((size_t)channels * sizeof(float));
+    memcpy(sc, scales, (size_t)channels * sizeof(float));
     snprintf(net->fp8_layers[net->n_fp8].name, sizeof net->fp8_layers[0].name, "%s", conv_name);
-    net->fp8_layers[net->n_fp8++].act_scale = act_scale;
+    net->fp8_layers[net->n_fp8].sc = sc;
+    net->fp8_layers[net->n_fp8++].c = channels;
     return 0;
 }
 int orc_net_num_priors(const orc_net* net) { return net->P; }

@@ -48,7 +48,7 @@ def main():
     heads = [eng.output(i) for i in range(4)]
     net = O.Net(a.backbone, S, 81, blob=blob)
     lay = {}
-    for name, sc in eng.fp8_layers():
+    for name, sc in eng.fp8_channel_scales():
         for nm in ([f"{name}{l}" for l in range(5)] if name == "head_t" else [name]):
             lay[nm] = sc
     pri = net.priors()

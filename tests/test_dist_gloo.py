@@ -110,6 +110,32 @@ def test_measured_traffic_reads_the_committed_pmc_file():
     t, src = bench.measured_traffic("conv_igemm_f16<256,256,2,4,0,2,mfma16>", 64)
     assert src and src.startswith("profiles/") and t > 1e8
     assert bench.measured_traffic("no_such_kernel", 64) == (None, None)
+    # a tile FAMILY ({symbol: launches per step}): launch-weighted mean over its symbols; None unless every member was measured
+    fam = {"conv_igemm_f16<256,256,2,4,0,2,mfma16>": 5, "conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]": 1, "conv_igemm_f16<256,256,2,4,0,2,mfma16>[ml]": 2}
+    tf, _ = bench.measured_traffic(fam, 64)
+    assert tf is not None and t < tf < 8e8
+    assert bench.measured_traffic(dict(fam, no_such_kernel=1), 64) == (None, None)
+
+
+def test_roofline_groups_by_tile_family_and_records_say_how_weights_were_replicated():
+    """the headline roofline describes the step's largest tile FAMILY (the 256 x 256 tile is three kernel
+    symbols), and kernel_family() strips exactly the template flags."""
+    import bench
+    assert bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]") == "conv_igemm_f16<256,256,2,4,0,2>"
+    assert bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>[ml]") == bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>")
+    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1>[3x3]") == "conv_igemm_f16<128,128,2,2,0,1>" != bench.kernel_family("conv_igemm_f16<128,128,2,2,0,2>")
+    assert bench.kernel_family("bneck_chain_f16<64,256,next>") == "bneck_chain_f16<64,256,next>" and bench.kernel_family("det_masks") == "det_masks"
+    prof = [dict(name="conv_igemm_f16<128,128,2,2,0,1>:a", ms=2.0, flops=1e12, bytes=6e9),
+            dict(name="conv_igemm_f16<256,256,2,4,0,2,mfma16>:p", ms=1.5, flops=1.5e12, bytes=1e9),
+            dict(name="conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]:q", ms=1.2, flops=1.4e12, bytes=0.6e9),
+            dict(name="conv_igemm_f16<256,256,2,4,0,2,mfma16>[ml]:h", ms=0.9, flops=0.9e12, bytes=0.7e9)]
+    r = bench.roofline_of(prof, 64)
+    assert r["kernel"] == "conv_igemm_f16<256,256,2,4,0,2>" and r["launches"] == 3 and r["bound"] == "mfma" and len(r["symbols"]) == 3
+    assert abs(r["share_of_step"] - 3.6 / 5.6) < 1e-3 and abs(r["achieved"] - 3.8e12 / 3.6e-3 / 1e12) < 0.5
+    fams = bench.family_rooflines(prof)
+    assert [f["kernel"] for f in fams][0] == "conv_igemm_f16<128,128,2,2,0,1>" and all("family" in f for f in fams)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("weights_replication=") >= 2 and '"weights_replication": how' in src   # batch1 and configs4 carry their own field beside the headline's
 
 
 class _FakeEngine:
@@ -152,10 +178,12 @@ def _worker_deadline(rank, world, port, out_dir):
     try:
         bench.LIBRARY_BROADCAST_DEADLINE_S = 1
         eng = _FakeEngine(rank, 4096, hang_s=20)
-        how = bench.replicate_weights(_FakeYa, torch, dist, rank, world, 0, eng, 3, use_library=True, device="cpu")
-        np.save(os.path.join(out_dir, f"w{rank}.npy"), eng.loaded)
+        how, holder = bench.replicate_weights(_FakeYa, torch, dist, rank, world, 0, eng, 3, use_library=True, device="cpu",
+                                              make_engine=lambda: _FakeEngine(rank, 4096, hang_s=20))
+        np.save(os.path.join(out_dir, f"w{rank}.npy"), holder.loaded)
         with open(os.path.join(out_dir, f"how{rank}.txt"), "w") as f:
-            f.write(how + "\n" + str(bench._LIBRARY_CALL_STUCK))
+            # (a stuck rank's first engine belongs to the blocked thread: the weights went into a FRESH one and the old one was not touched)
+            f.write(how + "\n" + str(bench._LIBRARY_CALL_STUCK) + "\n" + str(holder is eng) + "\n" + str(eng.loaded is None))
     finally:
         dist.destroy_process_group()
     os._exit(0)   # (rank 1's helper thread is still asleep in the fake library call: what bench.main does in that case)
@@ -175,3 +203,5 @@ def test_library_broadcast_that_hangs_on_one_rank_falls_back_within_its_deadline
     assert how0[0].startswith("torch.distributed.broadcast") and how1[0].startswith("torch.distributed.broadcast")
     assert "failed on rank 0" in how0[0] and "did not return within 1 s on rank 1" in how1[0]
     assert how0[1] == "False" and how1[1] == "True"
+    assert how0[2] == "True"                              # rank 0's call failed cleanly: its engine keeps the weights
+    assert how1[2] == "False" and how1[3] == "True"       # rank 1's call is stuck: a fresh engine holds them, the first one was never touched again

@@ -1,7 +1,7 @@
 """-m gpu: the fp8 forward (yh_config.precision = YH_PRECISION_FP8; BASELINE.json configs[4]).
 The K-heavy 3x3 convolutions read OCP E4M3 operands on the block-scaled fp8 MFMA, everything else stays f16.
-Parity = HIP engine vs the oracle's fp8 mode (oracle/orc_net.c: the same convolutions named, the same per-tensor
-activation scales, per-channel weight scales derived the same way): heads within a stated tolerance, tail bit-exact on
+Parity = HIP engine vs the oracle's fp8 mode (oracle/orc_net.c: the same convolutions named, the same per-input-channel
+activation scales folded into the weights, per-output-channel weight scales derived the same way): heads within a stated tolerance, tail bit-exact on
 the engine's own heads. The fp8-vs-f16 gap is a property of the configuration and is reported with its own bound.
 The reference's model is quantised end to end too (uint8, data/README.md:5-10); nothing in it pins E4M3: parity unpinned."""
 import numpy as np
@@ -46,9 +46,13 @@ def test_fp8_needs_scales_and_lists_its_layers(fp8_setup):
     for never in ("l2b0_b", "l1b0_b", "head_out", "proto", "lat3", "l3b0_a"):
         assert never not in names, never                 # < 256 input channels, 1x1, or 351 output channels: f16
     eng.fp8_calibrate()
-    sc = dict(eng.fp8_layers())
-    assert all(0.0 < v < 1e3 for v in sc.values())
-    assert sc["p6"] == sc["head_t"] == sc["proto0"]      # one scale per TENSOR: P3..P7 live in one pyramid buffer
+    sc = dict(eng.fp8_channel_scales())
+    assert all(v.dtype == np.float32 and ((0.0 < v) & (v < 1e3)).all() for v in sc.values())
+    assert sc["l3b0_b"].shape == (256,) and sc["l4b1_b"].shape == (512,) and sc["head_t"].shape == (256,)
+    # scales belong to the TENSOR: P3..P7 live in one pyramid buffer, so its readers share one vector of channel scales
+    assert np.array_equal(sc["p6"], sc["head_t"]) and np.array_equal(sc["p6"], sc["proto0"])
+    assert len(np.unique(sc["p3"])) > 16                  # round 4: one scale per input CHANNEL, not per tensor
+    assert all(np.float32(v) == sc[n].max() for n, v in eng.fp8_layers())   # (yh_fp8_layer_info reports the largest)
 
 
 def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
@@ -66,9 +70,9 @@ def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
     eng.evaluate()
     got = [eng.output(i) for i in range(4)]
     net = oracle.Net(50, S, 81, blob=blob)
-    net.set_fp8(_expand(eng.fp8_layers()))
+    net.set_fp8(_expand(eng.fp8_channel_scales()))
     want = net.forward(img, f16=True)
-    sc = dict(eng.fp8_layers())
+    sc = dict(eng.fp8_channel_scales())
     consumer = {"l3b0_a": "l3b0_b", "p5": "head_t", "p3": "head_t", "p7": "head_t", "proto1": "proto2"}
     # Intermediate tensors. A tensor that only fp8 convolutions read exists in the engine only as E4M3 codes (what
     # yh_debug_read_tensor returns is their decoded value), while the oracle stores it in f16 and quantises where it
@@ -81,10 +85,10 @@ def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
         bound = (tol + (0.0625 if q_only else 0.0)) * max(1.0, np.abs(b).max())
         print(f"fp8 engine vs fp8 oracle {name}: max |err| {np.abs(a - b).max():.4f} = {100 * np.abs(a - b).max() / max(1.0, np.abs(b).max()):.2f} % of absmax (bound {100 * bound / max(1.0, np.abs(b).max()):.1f} %)")
         assert np.abs(a - b).max() <= bound, (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
-        if q_only:   # and every decoded value is an E4M3 value times the tensor's scale
-            s_t = sc[consumer[name]]
+        if q_only:   # and every decoded value is an E4M3 value times its channel's scale
+            s_t = sc[consumer[name]].astype(np.float64)
             table = np.sort(oracle.e4m3_decode_table()[np.isfinite(oracle.e4m3_decode_table())].astype(np.float64))
-            q = a.astype(np.float64).ravel() / s_t
+            q = (a.astype(np.float64) / s_t).ravel()
             near = table[np.clip(np.searchsorted(table, q), 1, len(table) - 1)]
             near2 = table[np.clip(np.searchsorted(table, q), 1, len(table) - 1) - 1]
             err = np.minimum(np.abs(q - near), np.abs(q - near2))
@@ -108,35 +112,37 @@ def test_fp8_forward_vs_fp8_oracle(fp8_setup, oracle):
 
 def test_fp8_single_layers_are_tight(fp8_setup, oracle):
     """One fp8 convolution at a time on identical inputs: the engine's own E4M3 input tensor (decoded exactly), the blob's
-    weights quantised per output channel as DESIGN.md §Precision states, f32 convolution of the decoded operands by the
-    oracle, y = relu(fma(acc, s_x * s_w, bias)) rounded to f16 - against the engine's output of that layer. What differs
+    weights with the input tensor's channel scales folded in along K and then quantised per output channel as DESIGN.md
+    §Precision states, f32 convolution of the decoded operands by the oracle, y = relu(fma(acc, s_w, bias)) rounded to f16 -
+    against the engine's output of that layer. What differs
     is the summation: 2 f16 ulp + 2^-10 of the sum of |products| (measured: 2^-13 - the block-scaled MFMA adds its 128
     products per instruction with a bounded internal alignment, exact on small integers as tests/test_gpu_ops.py shows). Covers a backbone 3x3 (l3b0_b), a protonet conv (proto1) and the multi-level
     shared head trunk on all five pyramid levels (a tap that left its level would be an O(1) error)."""
     import bench
     eng, blob, img, S = fp8_setup
     eng.set_input(img); eng.fp8_calibrate(); eng.evaluate()
-    sc = dict(eng.fp8_layers())
+    sc = dict(eng.fp8_channel_scales())
     convs = bench.parse_blob(blob)
     table = oracle.e4m3_decode_table()
 
-    def fq_weights(w):   # [cout][k][k][cin] -> decoded E4M3 values and the per-channel scale
-        aw = np.abs(w).reshape(w.shape[0], -1).max(1).astype(np.float32)
+    def fq_weights(w, s_c):   # [cout][k][k][cin], channel scales [cin] -> decoded E4M3 values of t = w * s_c and the per-output-channel scale
+        t = (w.astype(np.float32) * s_c.astype(np.float32)).astype(np.float32)
+        aw = np.abs(t).reshape(t.shape[0], -1).max(1).astype(np.float32)
         sw = np.where(aw > 0, aw / np.float32(448.0), np.float32(1.0)).astype(np.float32)
         inv = (np.float32(1.0) / sw).astype(np.float32)
-        q = np.stack([table[oracle.quantize_e4m3(w[o], float(inv[o]))] for o in range(w.shape[0])])
+        q = np.stack([table[oracle.quantize_e4m3(t[o], float(inv[o]))] for o in range(t.shape[0])])
         return q.astype(np.float32), sw
 
     def check(layer, x_name, y_name, conv_index, stride=1):
-        s_x = np.float32(sc[layer])
+        s_x = sc[layer]                                  # one scale per input channel
         xq = table[oracle.quantize_e4m3((eng.tensor(x_name).astype(np.float32) / s_x).astype(np.float32), 1.0)]   # the codes' exact values
         assert np.abs(xq * s_x - eng.tensor(x_name)).max() <= 1e-6 * np.abs(xq * s_x).max()
         w, b = convs[conv_index]
-        wq, sw = fq_weights(w)
+        wq, sw = fq_weights(w, s_x)
         zero = np.zeros(w.shape[0], np.float32)
         acc = oracle.conv2d(xq, wq, zero, stride, 1, None, 0, f16=False)
-        mag = oracle.conv2d(np.abs(xq), np.abs(wq), zero, stride, 1, None, 0, f16=False) * (s_x * sw)   # sum of |products|, in output units
-        want = np.maximum(acc * (s_x * sw) + b, 0).astype(np.float16).astype(np.float32)
+        mag = oracle.conv2d(np.abs(xq), np.abs(wq), zero, stride, 1, None, 0, f16=False) * sw   # sum of |products|, in output units
+        want = np.maximum(acc * sw + b, 0).astype(np.float16).astype(np.float32)
         got = eng.tensor(y_name)
         ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10
         err = np.abs(got - want)
@@ -177,12 +183,32 @@ def test_fp8_scales_can_be_set_layer_by_layer(fp8_setup):
     eng, blob, img, S = fp8_setup
     eng.set_input(img); eng.fp8_calibrate(); eng.evaluate()
     heads = [eng.output(i) for i in range(4)]
-    layers = eng.fp8_layers()
+    layers = eng.fp8_channel_scales()
     e2 = ya.Engine(input_size=S, max_batch=2, use_graph=False, precision=ya.PRECISION_FP8, conf_thresh=TH)
+    for i, (_, sc) in enumerate(layers[:5]):
+        e2.fp8_set_layer_scale(i, sc)                     # (scales stored with a model may be set BEFORE its weights are loaded ...)
     e2.load_weights(blob)
     for i, (_, sc) in enumerate(layers):
-        e2.fp8_set_layer_scale(i, sc)
+        if i >= 5:
+            e2.fp8_set_layer_scale(i, sc)                 # (... or after)
     e2.set_input(img); e2.evaluate()
     for i in range(4):
         assert np.array_equal(e2.output(i), heads[i])
+    with pytest.raises(ya.YhError):
+        e2.fp8_set_layer_scale(0, layers[0][1][:8])       # wrong channel count
     e2.close()
+    # yh_config.fp8_per_tensor = 1 (round 3's scheme): every channel of a tensor gets the tensor's scale, and ONE number per layer
+    # (yh_fp8_set_layer_scale) reproduces that calibrated forward bit for bit
+    t1 = ya.Engine(input_size=S, max_batch=2, use_graph=False, precision=ya.PRECISION_FP8, conf_thresh=TH, fp8_per_tensor=True)
+    t1.load_weights(blob)
+    t1.set_input(img); t1.fp8_calibrate(); t1.evaluate()
+    assert all(len(np.unique(v)) == 1 for _, v in t1.fp8_channel_scales())
+    assert not np.array_equal(t1.output(1), heads[1])     # (a different quantisation from the per-channel one)
+    t2 = ya.Engine(input_size=S, max_batch=2, use_graph=False, precision=ya.PRECISION_FP8, conf_thresh=TH)
+    t2.load_weights(blob)
+    for i, (_, v) in enumerate(t1.fp8_layers()):
+        t2.fp8_set_layer_scale(i, v)
+    t2.set_input(img); t2.evaluate()
+    for i in range(4):
+        assert np.array_equal(t2.output(i), t1.output(i))
+    t1.close(); t2.close()

@@ -46,27 +46,30 @@ class Forced:
         self.O, self.convs, self.idx, self.table = oracle, bench.parse_blob(blob), conv_indices(backbone), oracle.e4m3_decode_table()
         self._wq = {}
 
-    def weights(self, name):
+    def weights(self, name, s_c):
+        """The layer's weights with its input tensor's channel scales folded in along K (t = w * s_c, one f32 multiplication), then
+        one scale per output channel and E4M3 codes of t / s_w - engine.hip: refresh_fp8_scales, oracle/orc_net.c: run_conv."""
         if name not in self._wq:
             w, b = self.convs[self.idx[name]]
-            aw = np.abs(w).reshape(w.shape[0], -1).max(1).astype(np.float32)
+            t = (w.astype(np.float32) * s_c.astype(np.float32)).astype(np.float32)
+            aw = np.abs(t).reshape(t.shape[0], -1).max(1).astype(np.float32)
             sw = np.where(aw > 0, aw / np.float32(448.0), np.float32(1.0)).astype(np.float32)
             inv = (np.float32(1.0) / sw).astype(np.float32)
-            wq = np.stack([self.table[self.O.quantize_e4m3(w[o], float(inv[o]))] for o in range(w.shape[0])]).astype(np.float32)
+            wq = np.stack([self.table[self.O.quantize_e4m3(t[o], float(inv[o]))] for o in range(t.shape[0])]).astype(np.float32)
             self._wq[name] = (wq, sw, b)
         return self._wq[name]
 
-    def expect(self, name, x_f32, s_x, stride, relu):
-        """x_f32: the engine's input tensor [1][h][w][c] (f16 values, or exactly decoded E4M3 values). Returns (want f16-rounded,
-        sum of |products| in output units)."""
-        s_x = np.float32(s_x)
-        inv = float(np.float32(1.0) / s_x)                       # the epilogue multiplies by 1 / s (engine.hip: y8_inv_scale)
-        xq = self.table[self.O.quantize_e4m3(x_f32.astype(np.float32), inv)].astype(np.float32)
-        wq, sw, b = self.weights(name)
+    def expect(self, name, x_f32, s_c, stride, relu):
+        """x_f32: the engine's input tensor [1][h][w][c] (f16 values, or exactly decoded E4M3 values); s_c: its channel scales [c].
+        Returns (want f16-rounded, sum of |products| in output units)."""
+        s_c = np.asarray(s_c, np.float32)
+        inv = (np.float32(1.0) / s_c).astype(np.float32)         # the epilogue multiplies by 1 / s[c] (engine.hip: y8_inv)
+        xq = self.table[self.O.quantize_e4m3((x_f32.astype(np.float32) * inv).astype(np.float32), 1.0)].astype(np.float32)
+        wq, sw, b = self.weights(name, s_c)
         zero = np.zeros(wq.shape[0], np.float32)
         acc = self.O.conv2d(xq, wq, zero, stride, 1, None, 0, f16=False)
-        mag = self.O.conv2d(np.abs(xq), np.abs(wq), zero, stride, 1, None, 0, f16=False) * (s_x * sw)
-        v = acc * (s_x * sw) + b
+        mag = self.O.conv2d(np.abs(xq), np.abs(wq), zero, stride, 1, None, 0, f16=False) * sw
+        v = acc * sw + b
         if relu:
             v = np.maximum(v, 0)
         return v.astype(np.float16).astype(np.float32), mag
@@ -101,7 +104,7 @@ def r101_fp8(built, oracle):
     D = ya.Engine(input_size=S7, backbone=101, max_batch=NB, use_graph=False, precision=ya.PRECISION_FP8, debug_tensors=True)
     D.load_weights(blob)
     assert [n for n, _ in D.fp8_layers()] == [n for n, _ in P.fp8_layers()]
-    for i, (_, sc) in enumerate(P.fp8_layers()):
+    for i, (_, sc) in enumerate(P.fp8_channel_scales()):
         D.fp8_set_layer_scale(i, sc)
     D.set_input(frames)
     D.evaluate()
@@ -111,8 +114,8 @@ def r101_fp8(built, oracle):
 
 def test_all_36_fp8_launches_teacher_forced_r101_700(r101_fp8):
     P, D, blob, frames, forced = r101_fp8
-    sc = dict(D.fp8_layers())
-    assert len(sc) == 36
+    sc = dict(D.fp8_channel_scales())
+    assert len(sc) == 36 and all(np.array_equal(v, dict(P.fp8_channel_scales())[n]) for n, v in sc.items())
     # which tile each launch took (yh_profile_run names): all three fp8 tiles and the multi-level 256 x 256 form are in the sweep
     names = [p["name"] for p in D.profile(with_tail=False, reps=1)]
     fp8_names = [n for n in names if n.startswith("conv_igemm_fp8<")]
@@ -155,7 +158,7 @@ def test_production_fp8_engine_e4m3_only_tensors_and_fused_prototype_conv(r101_f
     import bench
     import yolact_amd as ya
     P, D, blob, frames, forced = r101_fp8
-    sc = dict(P.fp8_layers())
+    sc = dict(P.fp8_channel_scales())
     names = [p["name"] for p in P.profile(with_tail=False, reps=1)]
     assert "conv_igemm_fp8<256,256,2,4>[+1x1]:proto3+proto" in names, [n for n in names if "proto" in n]
     with pytest.raises(ya.YhError):
@@ -169,8 +172,8 @@ def test_production_fp8_engine_e4m3_only_tensors_and_fused_prototype_conv(r101_f
             continue
         want, mag = forced.expect(layer, P.tensor_frame(xin, f)[None], sc[layer], stride, relu)
         got = P.tensor_frame(yout, f)[None]
-        s_out = np.float32(sc[consumer[yout]])                     # the scale of the tensor this layer writes
-        q = got.astype(np.float64).ravel() / s_out                 # every decoded value is a code value times the scale
+        s_out = sc[consumer[yout]].astype(np.float32)              # the channel scales of the tensor this layer writes
+        q = (got.astype(np.float64) / s_out).ravel()               # every decoded value is a code value times its channel's scale
         near = np.abs(codes[np.clip(np.searchsorted(codes, q), 1, len(codes) - 1)] - q)
         near = np.minimum(near, np.abs(codes[np.clip(np.searchsorted(codes, q), 1, len(codes) - 1) - 1] - q))
         assert (near <= 1e-5 * np.maximum(1.0, np.abs(q))).all(), layer
@@ -202,15 +205,16 @@ def test_fp8_detections_vs_fp8_oracle_above_the_head_noise(r101_fp8, oracle):
       * decisions - every detection whose score clears the 0.05 threshold by that factor (score > 0.091) is a detection of the
         other side too, up to max(3, 20 %) of them (measured: 0 of 16 and 3 of 19 on the noise frame - their probabilities agree
         (continuity), but Fast-NMS is a second discrete decision: with untrained box regressions a neighbour's IoU straddles 0.5);
-      * masks - over matched pairs with at least 500 mask pixels: pixel-weighted IoU >= 0.5 and median IoU >= 0.4 (measured 0.67 / 0.54
-        on noise, 0.86 / 0.88 on frc_balls; the prototypes differ by 6 % rms around the sigmoid's 0.5 level).
-    The same figures against the F16 oracle are printed, not asserted: that gap is the price of the precision, not a parity claim."""
+      * masks - over matched pairs with at least 500 mask pixels: pixel-weighted IoU and median IoU >= 0.5 on the noise frame,
+        >= 0.65 / 0.6 on frc_balls (the prototypes differ by 6 % rms around the sigmoid's 0.5 level).
+    Against the F16 oracle - the price of the precision, not a parity claim - the figures are printed for the noise frame and,
+    since round 4, asserted on frc_balls (below)."""
     P, D, blob, frames, forced = r101_fp8
     P.set_input(frames); P.evaluate()
     heads = [P.output(i) for i in range(4)]
     net = oracle.Net(101, S7, 81, blob=blob)
     lay = {}
-    for name, sc in P.fp8_layers():
+    for name, sc in P.fp8_channel_scales():
         for nm in ([f"{name}{l}" for l in range(5)] if name == "head_t" else [name]):
             lay[nm] = sc
     pri = net.priors()
@@ -253,11 +257,17 @@ def test_fp8_detections_vs_fp8_oracle_above_the_head_noise(r101_fp8, oracle):
         print(f"frame {f}: oracle {len(od)} / engine {len(ed)} detections, matched {len(set(ek) & set(ok_))}; max |log prob ratio| {worst:.3f}; "
               f"above margin: oracle {len(strong_o)} (unmatched {miss_o}), engine {len(strong_e)} (unmatched {miss_e}); "
               f"{len(v)} mask pairs: pixel-weighted IoU {weighted:.3f}, median {np.median(v):.3f}")
-        assert worst <= 0.6, (f, worst)
+        real = f == NB - 1                      # the reference's test image: a handful of confident detections, not a list of threshold cases
+        # (round 4, per-input-channel scales - measured: noise 0.508, 1 / 14 and 2 / 15 unmatched, 0.60 / 0.65; frc_balls 0.234, 0 / 1 and 0 / 2, 0.76 / 0.74)
+        assert worst <= (0.35 if real else 0.6), (f, worst)
         assert miss_o <= max(3, len(strong_o) // 5) and miss_e <= max(3, len(strong_e) // 5), (f, miss_o, len(strong_o), miss_e, len(strong_e))
-        assert len(v) >= 3 and weighted >= 0.5 and np.median(v) >= 0.4, (f, len(v), weighted, float(np.median(v)))
-        # reported: the same engine detections against the f16 oracle
+        assert len(v) >= 3 and weighted >= (0.65 if real else 0.5) and np.median(v) >= (0.6 if real else 0.5), (f, len(v), weighted, float(np.median(v)))
+        # the same engine detections against the F16 oracle - the price of the precision. Reported for the noise frame; ASSERTED
+        # (round 4) on the reference's test image at 700 x 700: every detection of the f16 oracle but at most one is a detection of
+        # the fp8 engine, with a mask IoU over the matched pairs of at least 0.70 (measured: 8 of 8, 0.78)
         import bench
         w16 = net.forward(frames[f:f + 1], f16=True)
         acc = bench.accuracy_vs_oracle((ed, em), oracle.detect(w16[0][0], w16[1][0], w16[2][0], w16[3][0], pri))
-        print(f"frame {f}: fp8 engine vs f16 oracle: matched {acc['matched_class_and_prior']} of {acc['oracle_dets']}, mask IoU matched {acc['mask_iou_matched']}")
+        print(f"frame {f}: fp8 engine vs f16 oracle: matched {acc['matched_class_and_prior']} of {acc['oracle_dets']} (engine {acc['engine_dets']}), mask IoU matched {acc['mask_iou_matched']}, all {acc['mask_iou_all']}")
+        if real:
+            assert acc["oracle_dets"] >= 5 and acc["unmatched_oracle"] <= 1 and acc["unmatched_engine"] <= 2 and acc["mask_iou_matched"] >= 0.70, acc

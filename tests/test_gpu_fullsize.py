@@ -325,7 +325,7 @@ def test_yolact700_r101_fp8_one_frame_vs_fp8_oracle(built, oracle):
     dets = [eng.detections(f) for f in range(3)]
     net = oracle.Net(101, S7, 81, blob=blob)
     lay = {}
-    for name, sc in layers:
+    for name, sc in eng.fp8_channel_scales():             # one scale per input channel (round 4), folded into the weights on both sides
         for nm in ([f"{name}{l}" for l in range(5)] if name == "head_t" else [name]):
             lay[nm] = sc
     net.set_fp8(lay)

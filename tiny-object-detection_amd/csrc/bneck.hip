@@ -586,8 +586,8 @@ __global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
                     unsigned lo = 0, hi = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * p.a_next8_inv_scale) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv_scale) << (8 * e);
+                        lo |= e4m3_code((float)o[e] * p.a_next8_inv[kt * 64 + lc * 8 + e]) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv[kt * 64 + lc * 8 + 4 + e]) << (8 * e);
                     }
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(512, 1) void bneck_xn128_f16(const BneckParams p) {
                     unsigned lo = 0, hi = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * p.a_next8_inv_scale) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv_scale) << (8 * e);
+                        lo |= e4m3_code((float)o[e] * p.a_next8_inv[kt * 64 + lc * 8 + e]) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv[kt * 64 + lc * 8 + 4 + e]) << (8 * e);
                     }
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }

@@ -628,10 +628,11 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     if (p.y) *(half8*)(p.y + yo) = o;
                     if (p.y8) {   // fp8 precision: this tensor feeds an fp8 convolution (quantised from the f16-rounded value)
                         unsigned lo = 0, hi = 0;
+                        const f32x4 i0 = *(const f32x4*)(p.y8_inv + ch), i1 = *(const f32x4*)(p.y8_inv + ch + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            lo |= e4m3_code((float)o[e] * p.y8_inv_scale) << (8 * e);
-                            hi |= e4m3_code((float)o[4 + e] * p.y8_inv_scale) << (8 * e);
+                            lo |= e4m3_code((float)o[e] * i0[e]) << (8 * e);
+                            hi |= e4m3_code((float)o[4 + e] * i1[e]) << (8 * e);
                         }
                         *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
                     }
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
     if (p.y8) {
         unsigned lo = 0, hi = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * p.y8_inv_scale) << (8 * e); hi |= e4m3_code((float)o[4 + e] * p.y8_inv_scale) << (8 * e); }
+        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * p.y8_inv[ch + e]) << (8 * e); hi |= e4m3_code((float)o[4 + e] * p.y8_inv[ch + 4 + e]) << (8 * e); }
         *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
     }
 }

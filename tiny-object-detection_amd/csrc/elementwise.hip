@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_f16(const half_t* __restrict
 #define BIL_ROWS 4
 __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                     int h, int w, int c8, int ho, int wo,
-                                                    long long x_img_stride, long long y_img_stride, uint8_t* __restrict__ y8, float y8_inv) {
+                                                    long long x_img_stride, long long y_img_stride, uint8_t* __restrict__ y8, const float* __restrict__ y8_inv) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= wo * c8) return;
     const int ox = t / c8, cg = t - ox * c8, b = blockIdx.z, oy0 = blockIdx.y * BIL_ROWS;
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x
         }
         const long long yo = b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8;
         if (y) *(half8*)(y + yo) = o;
-        if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value)
+        if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value, one scale per channel)
             unsigned lo = 0, hi = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv) << (8 * e); }
+            for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv[cg * 8 + e]) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv[cg * 8 + 4 + e]) << (8 * e); }
             *(uint2*)(y8 + yo) = make_uint2(lo, hi);
         }
     }
@@ -155,12 +155,42 @@ __global__ __launch_bounds__(256) void quantize_e4m3_f16(const half_t* __restric
     y[t] = code;
 }
 
-// weight panel rows -> E4M3 with one scale per row (output channel): y[r][k] = e4m3(x[r][k] * inv_scale[r])
-__global__ __launch_bounds__(256) void quantize_rows_e4m3_f16(const half_t* __restrict__ x, uint8_t* __restrict__ y, int rows, int K,
-                                                              const float* __restrict__ inv_scale) {
+// weight panel rows -> E4M3 with one scale per row (output channel), the input tensor's per-channel activation scales folded into
+// the K axis first (K index = tap * C + c): y[r][k] = e4m3(((float)x[r][k] * col_scale[k % C]) * inv_scale[r])
+__global__ __launch_bounds__(256) void quantize_rows_e4m3_f16(const half_t* __restrict__ x, uint8_t* __restrict__ y, int rows, int K, int C,
+                                                              const float* __restrict__ col_scale, const float* __restrict__ inv_scale) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)rows * K) return;
-    y[t] = (uint8_t)e4m3_code((float)x[t] * inv_scale[t / K]);
+    const int k = (int)(t % K);
+    const float v = __fmul_rn((float)x[t], col_scale[k % C]);
+    y[t] = (uint8_t)e4m3_code(__fmul_rn(v, inv_scale[t / K]));
+}
+// ... and the row maxima max_k |(float)x[r][k] * col_scale[k % C]| that its row scales come from (one workgroup per row; bit
+// pattern of a non-negative float)
+__global__ __launch_bounds__(256) void rowmax_scaled_f16(const half_t* __restrict__ x, int K, int C, const float* __restrict__ col_scale, unsigned* __restrict__ out) {
+    __shared__ float red[4];
+    const half_t* row = x + (long long)blockIdx.x * K;
+    float m = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) { const float a = fabsf(__fmul_rn((float)row[k], col_scale[k % C])); m = a > m ? a : m; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { m = red[0]; for (int i = 1; i < 4; ++i) m = red[i] > m ? red[i] : m; out[blockIdx.x] = __float_as_uint(m); }
+}
+// max |x| per CHANNEL of an f16 tensor [rows][C] (C a multiple of 8, 256 % (C / 8) == 0), combined with atomicMax on bit patterns
+__global__ __launch_bounds__(256) void absmax_channels_f16(const half_t* __restrict__ x, long long rows, int C, unsigned* __restrict__ out) {
+    const int c8 = C >> 3, cg = threadIdx.x % c8, rl = threadIdx.x / c8, rpb = 256 / c8;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = 0.0f;
+    for (long long r = (long long)blockIdx.x * rpb + rl; r < rows; r += (long long)gridDim.x * rpb) {
+        const half8 v = *(const half8*)(x + r * C + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = fabsf((float)v[e]); m[e] = a > m[e] ? a : m[e]; }   // (NaN never wins)
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicMax(out + cg * 8 + e, __float_as_uint(m[e]));
 }
 
 // max |x| over an f16 range, as the bit pattern of a non-negative float (monotone as unsigned): one atomicMax per wave
@@ -176,7 +206,7 @@ __global__ __launch_bounds__(256) void absmax_f16(const half_t* __restrict__ x, 
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-__global__ __launch_bounds__(256) void dequant_e4m3_f32(const uint8_t* __restrict__ x, float* __restrict__ y, long long n, float scale) {
+__global__ __launch_bounds__(256) void dequant_e4m3_f32(const uint8_t* __restrict__ x, float* __restrict__ y, long long n, const float* __restrict__ scale_ch, int C) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const unsigned b = x[t], s = b >> 7, e = (b >> 3) & 15u, m = b & 7u;
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256) void dequant_e4m3_f32(const uint8_t* __restric
     if (e == 15u && m == 7u) v = __uint_as_float(0x7FC00000u);
     else if (e == 0u) v = (float)m * 0.001953125f;                          // m / 8 * 2^-6
     else v = __uint_as_float(((e + 120u) << 23) | (m << 20));               // (1 + m / 8) * 2^(e - 7)
-    y[t] = (s ? -v : v) * scale;
+    y[t] = (s ? -v : v) * scale_ch[t % C];
 }
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
@@ -198,12 +228,22 @@ hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, 
     return hipGetLastError();
 }
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
-                           long long xs, long long ys, hipStream_t s, uint8_t* y8, float y8_inv) {
+                           long long xs, long long ys, hipStream_t s, uint8_t* y8, const float* y8_inv) {
     hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)((ho + BIL_ROWS - 1) / BIL_ROWS), (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
     return hipGetLastError();
 }
-hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, const float* inv_scale_rows, hipStream_t s) {
-    hipLaunchKernelGGL(quantize_rows_e4m3_f16, dim3(nblk((long long)rows * K)), dim3(256), 0, s, x, y, rows, K, inv_scale_rows);
+hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, int C, const float* col_scale, const float* inv_scale_rows, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_rows_e4m3_f16, dim3(nblk((long long)rows * K)), dim3(256), 0, s, x, y, rows, K, C, col_scale, inv_scale_rows);
+    return hipGetLastError();
+}
+hipError_t launch_rowmax_scaled_f16(const half_t* x, int rows, int K, int C, const float* col_scale, unsigned* out_bits, hipStream_t s) {
+    hipLaunchKernelGGL(rowmax_scaled_f16, dim3((unsigned)rows), dim3(256), 0, s, x, K, C, col_scale, out_bits);
+    return hipGetLastError();
+}
+hipError_t launch_absmax_channels_f16(const half_t* x, long long rows, int C, unsigned* out_bits, hipStream_t s) {
+    if (C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return hipErrorInvalidValue;
+    const long long rpb = 256 / (C / 8), want = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(absmax_channels_f16, dim3((unsigned)(want < 1024 ? (want > 0 ? want : 1) : 1024)), dim3(256), 0, s, x, rows, C, out_bits);
     return hipGetLastError();
 }
 hipError_t launch_absmax_f16(const half_t* x, long long n, unsigned* out_bits, hipStream_t s) {
@@ -213,8 +253,8 @@ hipError_t launch_absmax_f16(const half_t* x, long long n, unsigned* out_bits, h
     hipLaunchKernelGGL(absmax_f16, dim3(grid ? grid : 1), dim3(256), 0, s, x, n8, out_bits);
     return hipGetLastError();
 }
-hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(dequant_e4m3_f32, dim3(nblk(n)), dim3(256), 0, s, x, y, n, scale);
+hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, const float* scale_ch, int C, hipStream_t s) {
+    hipLaunchKernelGGL(dequant_e4m3_f32, dim3(nblk(n)), dim3(256), 0, s, x, y, n, scale_ch, C);
     return hipGetLastError();
 }
 hipError_t launch_quantize_e4m3(const half_t* x, uint8_t* y, long long n, float inv_scale, hipStream_t s) {

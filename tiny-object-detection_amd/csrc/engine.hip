@@ -178,7 +178,15 @@ struct yh_engine {
     std::set<std::string> q_only;       // named tensors that exist only as E4M3 while fp8 is active
     bool fp8_active = false;            // the op list currently runs its fp8 form (false during calibration and in f16 engines)
     bool fp8_ready = false;             // scales calibrated
-    unsigned* absmax_dev = nullptr;
+    unsigned* absmax_dev = nullptr;     // calibration scratch: kMaxFp8Tensors x kMaxFp8Channels channel maxima (as bit patterns)
+    static constexpr int kMaxFp8Tensors = 64, kMaxFp8Channels = 512;
+    // Round 4: one activation scale per CHANNEL of every allocation an fp8 convolution reads (a per-tensor scale is the same value in
+    // every channel). The channel scale is folded into the consumer's weights along K before their per-output-channel quantisation
+    // (refresh_fp8_scales) and the producer's epilogue multiplies by the reciprocal table instead of a scalar: no extra pass.
+    std::vector<std::vector<float>> act_ch;   // by Buf::sid ([alloc_c] floats; empty: not set)
+    std::vector<int> alloc_c;                 // channels (= row stride in elements) of allocation sid
+    std::vector<float*> inv_dev, sc_dev;      // by sid: device tables of 1 / scale and scale ([alloc_c]; fp8 handles only)
+    unsigned* rowmax_dev = nullptr;           // [1024]: row maxima of a weight panel with the channel scales folded in
 
     // Two input buffers and a copy stream: yh_set_input_* fills the buffer the running step does NOT read, so frame k+1's
     // host -> device copy runs underneath step k (the limiter of the sharded path is host-side H2D). A step is
@@ -261,7 +269,15 @@ int new_buf(yh_engine* h, const char* name, int hh, int ww, int c, Buf* out) {
     b.zero = (half_t*)((char*)p + ((data_bytes + 15) & ~(size_t)15));
     b.sid = (int)h->act_scale.size();
     h->act_scale.push_back(1.0f); h->scale_set.push_back(0); h->alloc_base.push_back(b.d); h->alloc_img.push_back(b.img_stride);
+    h->act_ch.emplace_back(); h->alloc_c.push_back(c); h->inv_dev.push_back(nullptr); h->sc_dev.push_back(nullptr);
     if (h->cfg.precision == YH_PRECISION_FP8) {   // the E4M3 twin (288 GB of HBM: no aliasing games)
+        void* t = nullptr;
+        const std::vector<float> ones((size_t)c, 1.0f);
+        for (float** tab : { &h->inv_dev.back(), &h->sc_dev.back() }) {
+            if ((rc = dev_alloc(h, &t, (size_t)c * 4))) return rc;
+            if (hipMemcpy(t, ones.data(), (size_t)c * 4, hipMemcpyHostToDevice) != hipSuccess) return h->fail(YH_EHIP, "scale table upload");
+            *tab = (float*)t;
+        }
         const size_t qbytes = data_bytes / 2;
         rc = dev_alloc(h, &p, qbytes + 256);
         if (rc) return rc;
@@ -960,7 +976,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
         p.y = o.write_f16 ? o.out.d : nullptr;
-        if (o.write_q) { p.y8 = o.out.q; p.y8_inv_scale = 1.0f / h->act_scale[o.out.sid]; }
+        if (o.write_q) { p.y8 = o.out.q; p.y8_inv = h->inv_dev[o.out.sid]; }
         if (o.fp8) {
             // the loader's units stay 2 bytes: two E4M3 values (ConvParams: "fp8 form")
             const long long zq = o.in.qzero - o.in.q;
@@ -1140,7 +1156,7 @@ int fill_xn_params(yh_engine* h, const Op& oc, int n, BneckParams* out) {
     p.res_bytes = (unsigned)zr + 16u;
     p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias;
     p.a_next = (!h->fp8_active || oa.write_f16) ? oa.out.d : nullptr;
-    if (h->fp8_active && oa.write_q) { p.a_next8 = oa.out.q; p.a_next8_inv_scale = 1.0f / h->act_scale[oa.out.sid]; }
+    if (h->fp8_active && oa.write_q) { p.a_next8 = oa.out.q; p.a_next8_inv = h->inv_dev[oa.out.sid]; }
     p.stagger = h->tune.ablate >> 4;   // timing only (bneck_xn128_f16): bits 4-7 of tune.ablate drop the residual / y-store / W_c / W_a' stream
     *out = p;
     return YH_OK;
@@ -1187,7 +1203,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
         case OP_BILINEAR:
             if (h->fp8_active)
                 e = launch_bilinear(o.in.d, o.write_f16 ? o.out.d : nullptr, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream,
-                                    o.write_q ? o.out.q : nullptr, o.write_q ? 1.0f / h->act_scale[o.out.sid] : 1.0f);
+                                    o.write_q ? o.out.q : nullptr, o.write_q ? h->inv_dev[o.out.sid] : nullptr);
             else e = launch_bilinear(o.in.d, o.out.d, n, o.in.h, o.in.w, o.in.c, o.P, o.Q, o.in.img_stride, o.out.img_stride, h->stream);
             break;
         case OP_STEMPOOL: {
@@ -1398,13 +1414,49 @@ int check_blob(yh_engine* h, const uint8_t* b, size_t nbytes) {
     return YH_OK;
 }
 
-// Per-channel output scales of the fp8 convolutions: s_x of the input tensor (calibrated) * s_w[ch].
-int refresh_fp8_scales(yh_engine* h) {
+// One activation scale per channel of allocation `sid` (host copy, device tables of the scale and of its reciprocal).
+int set_sid_scales(yh_engine* h, int sid, const std::vector<float>& v) {
+    if ((int)v.size() != h->alloc_c[sid] || !h->inv_dev[sid]) return h->fail(YH_EINVAL, "fp8: channel scale count does not match the tensor");
+    std::vector<float> inv(v.size());
+    float mx = 0.0f;
+    for (size_t c = 0; c < v.size(); ++c) {
+        if (!(v[c] > 0.0f) || !(v[c] < 3.0e38f)) return h->fail(YH_EINVAL, "activation scale must be a positive finite number");
+        inv[c] = 1.0f / v[c];
+        mx = v[c] > mx ? v[c] : mx;
+    }
+    HIPCHK(h, hipMemcpy(h->inv_dev[sid], inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->sc_dev[sid], v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->act_ch[sid] = v;
+    h->act_scale[sid] = mx;      // (what yh_fp8_layer_info reports: the largest channel scale)
+    h->scale_set[sid] = 1;
+    return YH_OK;
+}
+
+// The E4M3 weights of the fp8 convolutions that read allocation `sid` (-1: all of them): the input tensor's channel scales s[c]
+// are folded into the K axis, then one scale per output channel - t = w * s[c], s_w = max_k |t| / 448 (1 for an all-zero row),
+// codes = e4m3(t * (1 / s_w)) by the device's own conversion - and the epilogue's multiplier is s_w alone
+// (y = fma(acc, s_w[ch], bias)). The same operations in the same order as oracle/orc_net.c's fp8 forward mode.
+int refresh_fp8_scales(yh_engine* h, int sid = -1) {
+    if (!h->weights_loaded) return YH_OK;
     for (Panel& p : h->panels) {
-        if (!p.fp8 || p.sw.empty()) continue;
-        std::vector<float> sc(p.coutPad);
-        for (int r = 0; r < p.coutPad; ++r) sc[r] = h->act_scale[p.in_sid] * p.sw[r];
-        HIPCHK(h, hipMemcpy(p.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        if (!p.fp8 || (sid >= 0 && p.in_sid != sid) || h->act_ch[p.in_sid].empty()) continue;
+        if (p.coutPad > 1024 || h->alloc_c[p.in_sid] != p.cin_store) return h->fail(YH_EINVAL, "fp8: weight panel geometry");
+        const float* col = h->sc_dev[p.in_sid];
+        if (launch_rowmax_scaled_f16(p.w, p.coutPad, p.Kpad, p.cin_store, col, h->rowmax_dev, h->stream) != hipSuccess) return h->fail(YH_EHIP, "weight row maxima launch failed");
+        std::vector<unsigned> bits(p.coutPad);
+        HIPCHK(h, hipMemcpyAsync(bits.data(), h->rowmax_dev, bits.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        p.sw.assign(p.coutPad, 1.0f);
+        std::vector<float> inv(p.coutPad, 1.0f);
+        for (int r = 0; r < p.coutPad; ++r) {
+            float a; memcpy(&a, &bits[r], 4);
+            p.sw[r] = a > 0.0f ? a / 448.0f : 1.0f;
+            inv[r] = 1.0f / p.sw[r];
+        }
+        HIPCHK(h, hipMemcpy(p.scale, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));   // (borrowed as the 1 / s_w table for this one launch)
+        if (launch_quantize_rows_e4m3(p.w, p.w8, p.coutPad, p.Kpad, p.cin_store, col, p.scale, h->stream) != hipSuccess) return h->fail(YH_EHIP, "weight quantisation launch failed");
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(p.scale, p.sw.data(), p.sw.size() * 4, hipMemcpyHostToDevice));
     }
     return YH_OK;
 }
@@ -1446,37 +1498,19 @@ int upload_panels(yh_engine* h, const uint8_t* blob) {
         }
         HIPCHK(h, hipMemcpy(p.w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(p.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-        if (p.fp8) {
-            // E4M3 weights, one scale per output channel: s_w = max |w| / 448 (1 for an all-zero row), codes =
-            // e4m3(w * (1 / s_w)) by the device's own conversion (the kernel yh_op_quantize_e4m3 tests against the oracle)
-            p.sw.assign(p.coutPad, 1.0f);
-            std::vector<float> inv(p.coutPad, 1.0f);
-            for (int r = 0; r < p.coutPad; ++r) {
-                float a = 0.0f;
-                for (int k = 0; k < p.Kpad; ++k) {
-                    const uint16_t b = w[(size_t)r * p.Kpad + k];
-                    _Float16 hv; memcpy(&hv, &b, 2);
-                    const float v = fabsf((float)hv);
-                    a = v > a ? v : a;
-                }
-                p.sw[r] = a > 0.0f ? a / 448.0f : 1.0f;
-                inv[r] = 1.0f / p.sw[r];
-            }
-            HIPCHK(h, hipMemcpy(p.scale, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));   // (borrowed as the 1 / s_w table for this one launch)
-            if (launch_quantize_rows_e4m3(p.w, p.w8, p.coutPad, p.Kpad, p.scale, h->stream) != hipSuccess) return h->fail(YH_EHIP, "weight quantisation launch failed");
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-        }
+        // (fp8 panels: the E4M3 codes depend on the input tensor's channel scales - refresh_fp8_scales makes them once those are known)
     }
     if (h->weights_loaded && h->cfg.precision == YH_PRECISION_FP8) {
         // a RE-load: the activation scales were calibrated for the old weights - they have to be set again (a first load
         // keeps scales that were stored with the model and set beforehand)
         std::fill(h->scale_set.begin(), h->scale_set.end(), 0);
+        for (auto& v : h->act_ch) v.clear();
         h->fp8_ready = false; h->fp8_active = false;
         for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
         h->graphs.clear();
     }
     h->weights_loaded = true;
-    if (h->fp8_ready) { const int rc = refresh_fp8_scales(h); if (rc) return rc; }
+    if (h->cfg.precision == YH_PRECISION_FP8) { const int rc = refresh_fp8_scales(h); if (rc) return rc; }   // (the panels whose input tensor already has its scales)
     return YH_OK;
 }
 
@@ -1570,8 +1604,10 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
     if (cfg->precision == YH_PRECISION_FP8) {
         plan_fp8(h);
         void* q = nullptr;
-        if ((rc = dev_alloc(h, &q, 256))) return bail(rc);
+        if ((rc = dev_alloc(h, &q, (size_t)yh_engine::kMaxFp8Tensors * yh_engine::kMaxFp8Channels * 4))) return bail(rc);
         h->absmax_dev = (unsigned*)q;
+        if ((rc = dev_alloc(h, &q, 1024 * 4))) return bail(rc);
+        h->rowmax_dev = (unsigned*)q;
     }
     {
         void* q = nullptr;
@@ -1662,20 +1698,43 @@ int yh_fp8_layer_info(const yh_engine* h, int32_t i, const char** conv_name, flo
     return YH_OK;
 }
 
-int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale) {
-    if (!h || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
-    if (!(act_scale > 0.0f) || !(act_scale < 3.0e38f)) return h->fail(YH_EINVAL, "activation scale must be a positive finite number");
+static int fp8_set_scales_impl(yh_engine* h, int32_t i, const std::vector<float>& v) {
     HIPCHK(h, hipSetDevice(h->dev));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // the scales are baked into the captured launches
     h->graphs.clear();
     const int sid = h->ops[h->fp8_ops[i]].in.sid;
-    h->act_scale[sid] = act_scale;
-    h->scale_set[sid] = 1;
-    // the handle counts as calibrated once EVERY E4M3 input tensor has a scale (scales are per tensor: layers that read
-    // one allocation - P3..P7 of the pyramid: p6, p7, head_t, proto0 - share theirs, include/yolact_hip.h)
+    const int rc = set_sid_scales(h, sid, v);
+    if (rc) return rc;
+    // the handle counts as calibrated once EVERY E4M3 input tensor has its scales (they belong to the tensor: layers that read
+    // one allocation - P3..P7 of the pyramid: p6, p7, head_t, proto0 - share them, include/yolact_hip.h)
     h->fp8_ready = fp8_missing(h).empty(); h->fp8_active = h->fp8_ready;
-    return h->weights_loaded ? refresh_fp8_scales(h) : YH_OK;
+    return refresh_fp8_scales(h, sid);
+}
+
+int yh_fp8_set_layer_scale(yh_engine* h, int32_t i, float act_scale) {
+    if (!h || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    if (!(act_scale > 0.0f) || !(act_scale < 3.0e38f)) return h->fail(YH_EINVAL, "activation scale must be a positive finite number");
+    return fp8_set_scales_impl(h, i, std::vector<float>((size_t)h->alloc_c[h->ops[h->fp8_ops[i]].in.sid], act_scale));
+}
+
+int yh_fp8_layer_channels(const yh_engine* h, int32_t i) {
+    if (!h || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    return h->alloc_c[h->ops[h->fp8_ops[i]].in.sid];
+}
+
+int yh_fp8_layer_channel_scales(const yh_engine* h, int32_t i, float* scales, int32_t n) {
+    if (!h || !scales || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    const int sid = h->ops[h->fp8_ops[i]].in.sid;
+    if (n != h->alloc_c[sid]) return YH_EINVAL;
+    for (int c = 0; c < n; ++c) scales[c] = h->act_ch[sid].empty() ? 1.0f : h->act_ch[sid][c];
+    return YH_OK;
+}
+
+int yh_fp8_set_layer_channel_scales(yh_engine* h, int32_t i, const float* scales, int32_t n) {
+    if (!h || !scales || i < 0 || i >= (int)h->fp8_ops.size()) return YH_EINVAL;
+    if (n != h->alloc_c[h->ops[h->fp8_ops[i]].in.sid]) return h->fail(YH_EINVAL, "fp8: channel scale count does not match the layer's input tensor");
+    return fp8_set_scales_impl(h, i, std::vector<float>(scales, scales + n));
 }
 
 int yh_fp8_calibrate(yh_engine* h) {
@@ -1688,42 +1747,56 @@ int yh_fp8_calibrate(yh_engine* h) {
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     h->graphs.clear();
     // 1. the f16 forward of these frames (every tensor in f16, as a YH_PRECISION_F16 handle computes it); 2. one scale per
-    // tensor that an fp8 convolution reads: max |x| / 448 (E4M3's largest finite value). On any failure the handle keeps the
-    // scales (and the form of the forward) it had.
+    // CHANNEL of every tensor that an fp8 convolution reads: max |x[.., c]| / 448 (E4M3's largest finite value; yh_config.
+    // fp8_per_tensor = 1: the tensor's maximum in every channel - round 3's scheme). On any failure the handle keeps the scales
+    // (and the form of the forward) it had.
     std::set<int> sids;
     for (int oi : h->fp8_ops) sids.insert(h->ops[oi].in.sid);
-    if (sids.size() > 64) return h->fail(YH_EINVAL, "too many fp8 input tensors");
-    unsigned bits[64];
+    constexpr int MT = yh_engine::kMaxFp8Tensors, MC = yh_engine::kMaxFp8Channels;
+    if ((int)sids.size() > MT) return h->fail(YH_EINVAL, "too many fp8 input tensors");
+    for (int sid : sids) if (h->alloc_c[sid] > MC) return h->fail(YH_EINVAL, "fp8 input tensor with more than 512 channels");
+    std::vector<unsigned> bits((size_t)MT * MC);
     h->fp8_active = false;
     const int rc = [&]() -> int {
         int r = wait_input(h);
         if (r) return r;
         r = enqueue_all(h, h->cur_n, 0);
         if (r) return r;
-        HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, 256, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->absmax_dev, 0, bits.size() * 4, h->stream));
         int k = 0;
         for (int sid : sids)
-            if (launch_absmax_f16(h->alloc_base[sid], (long long)h->cur_n * h->alloc_img[sid], h->absmax_dev + k++, h->stream) != hipSuccess)
+            if (launch_absmax_channels_f16(h->alloc_base[sid], (long long)h->cur_n * h->alloc_img[sid] / h->alloc_c[sid], h->alloc_c[sid], h->absmax_dev + (size_t)(k++) * MC, h->stream) != hipSuccess)
                 return h->fail(YH_EHIP, "absmax launch failed");
-        HIPCHK(h, hipMemcpyAsync(bits, h->absmax_dev, 256, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(bits.data(), h->absmax_dev, bits.size() * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         k = 0;
         for (int sid : sids) {   // (the maxima are combined as bit patterns of non-negative floats: Inf and every NaN compare above all finite values)
-            float a; memcpy(&a, &bits[k++], 4);
-            if (!(a < 3.0e38f)) {
-                std::string who;
-                for (int oi : h->fp8_ops) if (h->ops[oi].in.sid == sid) who += (who.empty() ? "" : ", ") + h->ops[oi].name;
-                return h->fail(YH_ESTATE, "fp8 calibration: the f16 forward of these frames overflowed (Inf / NaN) in the input tensor of " + who + "; no scale was changed");
+            for (int c = 0; c < h->alloc_c[sid]; ++c) {
+                float a; memcpy(&a, &bits[(size_t)k * MC + c], 4);
+                if (!(a < 3.0e38f)) {
+                    std::string who;
+                    for (int oi : h->fp8_ops) if (h->ops[oi].in.sid == sid) who += (who.empty() ? "" : ", ") + h->ops[oi].name;
+                    return h->fail(YH_ESTATE, "fp8 calibration: the f16 forward of these frames overflowed (Inf / NaN) in the input tensor of " + who + "; no scale was changed");
+                }
             }
+            ++k;
         }
         return YH_OK;
     }();
     if (rc) { h->fp8_active = h->fp8_ready; return rc; }
     int k = 0;
     for (int sid : sids) {
-        float a; memcpy(&a, &bits[k++], 4);
-        h->act_scale[sid] = a > 0.0f ? a / 448.0f : 1.0f;
-        h->scale_set[sid] = 1;
+        const int C = h->alloc_c[sid];
+        std::vector<float> v((size_t)C);
+        float amax = 0.0f;
+        for (int c = 0; c < C; ++c) { float a; memcpy(&a, &bits[(size_t)k * MC + c], 4); v[c] = a; amax = a > amax ? a : amax; }
+        for (int c = 0; c < C; ++c) {
+            const float a = h->cfg.fp8_per_tensor ? amax : v[c];
+            v[c] = a > 0.0f ? a / 448.0f : 1.0f;
+        }
+        const int r2 = set_sid_scales(h, sid, v);
+        if (r2) return r2;
+        ++k;
     }
     h->fp8_ready = true; h->fp8_active = true;
     return refresh_fp8_scales(h);
@@ -2219,7 +2292,7 @@ int yh_debug_read_tensor(yh_engine* h, const char* name, float* dst, size_t nflo
     for (int i = 0; i < n; ++i) {
         hipError_t e;
         if (h->fp8_active && h->q_only.count(name))
-            e = launch_dequant_e4m3_f32(b.q + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->act_scale[b.sid], h->stream);
+            e = launch_dequant_e4m3_f32(b.q + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->sc_dev[b.sid], b.c, h->stream);
         else e = launch_f16_to_f32(b.d + (long long)i * b.img_stride, h->out_f32 + (size_t)i * per, (long long)per, h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
     }
@@ -2246,7 +2319,7 @@ int yh_debug_read_tensor_frame(yh_engine* h, const char* name, int32_t frame, fl
     if (rc) return rc;
     hipError_t ce;
     if (h->fp8_active && h->q_only.count(name))   // fp8 precision: this tensor exists only as E4M3 codes
-        ce = launch_dequant_e4m3_f32(b.q + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->act_scale[b.sid], h->stream);
+        ce = launch_dequant_e4m3_f32(b.q + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->sc_dev[b.sid], b.c, h->stream);
     else ce = launch_f16_to_f32(b.d + (long long)frame * b.img_stride, h->out_f32, (long long)per, h->stream);
     if (ce != hipSuccess) return h->fail(YH_EHIP, "debug read convert");
     HIPCHK(h, hipMemcpyAsync(dst, h->out_f32, per * 4, hipMemcpyDeviceToHost, h->stream));

@@ -193,9 +193,11 @@ int yh_group_fp8_calibrate(yh_group* g) {
     const int nl = yh_fp8_layer_count(g->eng[0]);
     for (size_t i = 1; i < g->eng.size(); ++i)
         for (int l = 0; l < nl; ++l) {
-            float sc = 1.0f;
-            if ((rc = yh_fp8_layer_info(g->eng[0], l, nullptr, &sc))) return g->member_fail(0, rc);
-            if ((rc = yh_fp8_set_layer_scale(g->eng[i], l, sc))) return g->member_fail((int)i, rc);
+            const int nc = yh_fp8_layer_channels(g->eng[0], l);
+            if (nc < 1) return g->member_fail(0, YH_EINVAL);
+            std::vector<float> sc((size_t)nc, 1.0f);
+            if ((rc = yh_fp8_layer_channel_scales(g->eng[0], l, sc.data(), nc))) return g->member_fail(0, rc);
+            if ((rc = yh_fp8_set_layer_channel_scales(g->eng[i], l, sc.data(), nc))) return g->member_fail((int)i, rc);
         }
     return YH_OK;
 }

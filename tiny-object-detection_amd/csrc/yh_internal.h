@@ -62,9 +62,10 @@ struct ConvParams {
     // 2-byte units (two fp8 values), so the loader is the f16 one; out = acc * scale[ch] + bias
     const float* scale;
     // E4M3 output (fp8 precision: this tensor feeds an fp8 convolution): y8[same element offsets as y] =
-    // e4m3((float)(f16 result) * y8_inv_scale), round to nearest even, saturating. y may then be nullptr.
+    // e4m3((float)(f16 result) * y8_inv[channel]), round to nearest even, saturating - one (reciprocal) activation scale per
+    // channel of the tensor, [ldy] floats (round 4; a per-tensor scale is the same value everywhere). y may then be nullptr.
     uint8_t* y8;
-    float y8_inv_scale;
+    const float* y8_inv;
     // two-source form (x2 != nullptr; 1x1 convolutions only): K is the concatenation of x's C channels (k-steps
     // 0 .. k1steps-1) and of C2 channels of a SECOND tensor x2 [n][H2][W2][C2] read at stride2 (output pixel (p, q) <-
     // x2 pixel (p*stride2, q*stride2)); the weight panel holds [W1 row | W2 row] along K. A bottleneck block's last 1x1
@@ -133,7 +134,7 @@ struct BneckParams {
     int no_b;
     unsigned res_bytes;     // ... its residual rows travel by LDS-DMA: the buffer-descriptor range of res
     uint8_t* a_next8;
-    float a_next8_inv_scale;
+    const float* a_next8_inv;   // [planes] reciprocal scales, one per channel of a'
     int grid_cap;           // > 0: persistent grid of at most this many workgroups (each walks its tiles); 0: one workgroup per tile
     int stagger;            // > 0: the second-dispatched half of the grid starts this many 64-clock sleep units late (phase offset)
 };
@@ -161,12 +162,15 @@ hipError_t launch_preprocess(const uint8_t* rgb, half_t* out4, int n, int S, int
 hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo, hipStream_t s);
 // y and / or y8 (E4M3 of the f16 result * y8_inv_scale) may be written
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
-                           long long x_img_stride, long long y_img_stride, hipStream_t s, uint8_t* y8 = nullptr, float y8_inv_scale = 1.0f);
+                           long long x_img_stride, long long y_img_stride, hipStream_t s, uint8_t* y8 = nullptr, const float* y8_inv = nullptr);
 // fp8 precision helpers: weight rows -> E4M3 with one scale per row; |x| maximum of an f16 range (as the bit pattern
 // of a non-negative float, combined with atomicMax); E4M3 codes -> f32 (debug reads)
-hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, const float* inv_scale_rows, hipStream_t s);
+// (the input tensor's per-channel activation scales col_scale[C] are folded into the K axis first: K index = tap * C + c)
+hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, int C, const float* col_scale, const float* inv_scale_rows, hipStream_t s);
+hipError_t launch_rowmax_scaled_f16(const half_t* x, int rows, int K, int C, const float* col_scale, unsigned* out_bits, hipStream_t s);
 hipError_t launch_absmax_f16(const half_t* x, long long n, unsigned* out_bits, hipStream_t s);
-hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, float scale, hipStream_t s);
+hipError_t launch_absmax_channels_f16(const half_t* x, long long rows, int C, unsigned* out_bits, hipStream_t s);
+hipError_t launch_dequant_e4m3_f32(const uint8_t* x, float* y, long long n, const float* scale_ch, int C, hipStream_t s);
 // f32 -> E4M3 code, round to nearest even, saturating at +-448 (NaN keeps its sign with the NaN code)
 __device__ __forceinline__ unsigned e4m3_code(float v) {
     if (v != v) return ((__float_as_uint(v) >> 24) & 0x80u) | 0x7Fu;

@@ -46,7 +46,7 @@ class Config(C.Structure):
                 ("input_size", C.c_int32), ("max_batch", C.c_int32), ("num_classes", C.c_int32),
                 ("top_k", C.c_int32), ("max_dets", C.c_int32), ("conf_thresh", C.c_float),
                 ("nms_thresh", C.c_float), ("use_graph", C.c_int32), ("debug_tensors", C.c_int32),
-                ("precision", C.c_int32), ("fp8_f16_layers", C.c_int32), ("reserved", C.c_int32 * 5), ("tune", Tuning)]
+                ("precision", C.c_int32), ("fp8_f16_layers", C.c_int32), ("fp8_per_tensor", C.c_int32), ("reserved", C.c_int32 * 4), ("tune", Tuning)]
 
 
 class TensorInfo(C.Structure):
@@ -81,6 +81,9 @@ SYMBOLS = [
     ("yh_fp8_layer_count", _i, [_vp]),
     ("yh_fp8_layer_info", _i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_f)]),
     ("yh_fp8_set_layer_scale", _i, [_vp, _i, _f]),
+    ("yh_fp8_layer_channels", _i, [_vp, _i]),
+    ("yh_fp8_layer_channel_scales", _i, [_vp, _i, _vp, _i]),
+    ("yh_fp8_set_layer_channel_scales", _i, [_vp, _i, _vp, _i]),
     ("yh_group_broadcast_weights", _i, [C.POINTER(_vp), _i, _i]),
     ("yh_rccl_unique_id", _i, [_vp]),
     ("yh_rank_broadcast_weights", _i, [_vp, _vp, _i, _i, _i]),
@@ -217,7 +220,7 @@ class Engine:
 
     def __init__(self, input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100,
                  conf_thresh=0.05, nms_thresh=0.5, use_graph=True, device=0, debug_tensors=False, precision=PRECISION_F16,
-                 tune=None, fp8_f16_layers=0):
+                 tune=None, fp8_f16_layers=0, fp8_per_tensor=False):
         self.L = load_library()
         cfg = Config()
         self.L.yh_default_config(C.byref(cfg))
@@ -227,6 +230,7 @@ class Engine:
         cfg.debug_tensors = 1 if debug_tensors else 0
         cfg.precision = precision
         cfg.fp8_f16_layers = fp8_f16_layers
+        cfg.fp8_per_tensor = 1 if fp8_per_tensor else 0
         if tune:
             cfg.tune = Tuning.of(**tune)
         self._tune = dict(tune or {})
@@ -307,7 +311,25 @@ class Engine:
         return out
 
     def fp8_set_layer_scale(self, i, scale):
-        self._chk(self.L.yh_fp8_set_layer_scale(self.h, i, C.c_float(scale)))
+        """One number: the same scale in every channel of layer i's input tensor; an array: one per channel."""
+        if np.ndim(scale) == 0:
+            self._chk(self.L.yh_fp8_set_layer_scale(self.h, i, C.c_float(scale)))
+        else:
+            v = np.ascontiguousarray(scale, np.float32)
+            self._chk(self.L.yh_fp8_set_layer_channel_scales(self.h, i, _p(v), int(v.size)))
+
+    def fp8_channel_scales(self):
+        """[(conv name, per-input-channel activation scales as an f32 array)] of the E4M3 convolutions, in execution order -
+        what the oracle's fp8 forward mode is given (oracle.Net.set_fp8) and what a host stores with the model."""
+        out = []
+        for i, (name, _) in enumerate(self.fp8_layers()):
+            nc = self.L.yh_fp8_layer_channels(self.h, i)
+            if nc < 1:
+                raise YhError(nc, "yh_fp8_layer_channels")
+            v = np.empty(nc, np.float32)
+            self._chk(self.L.yh_fp8_layer_channel_scales(self.h, i, _p(v), nc))
+            out.append((name, v))
+        return out
 
     def rank_broadcast_weights(self, id_bytes, rank, nranks, root=0):
         """One process per GPU: RCCL broadcast of the root rank's weights (id_bytes from rccl_unique_id on one rank)."""
@@ -557,12 +579,16 @@ class Group:
         cfg = Config()
         self.L.yh_default_config(C.byref(cfg))
         kw = dict(input_size=550, backbone=50, max_batch=1, num_classes=81, top_k=200, max_dets=100, conf_thresh=0.05, nms_thresh=0.5,
-                  use_graph=True, debug_tensors=False, precision=PRECISION_F16, tune=None)
+                  use_graph=True, debug_tensors=False, precision=PRECISION_F16, tune=None, fp8_f16_layers=0, fp8_per_tensor=False)
+        unknown = set(engine_kw) - set(kw)
+        if unknown:
+            raise TypeError(f"Group: unknown engine keyword(s) {sorted(unknown)}")
         kw.update(engine_kw)
         cfg.backbone, cfg.input_size, cfg.max_batch = kw["backbone"], kw["input_size"], kw["max_batch"]
         cfg.num_classes, cfg.top_k, cfg.max_dets = kw["num_classes"], kw["top_k"], kw["max_dets"]
         cfg.conf_thresh, cfg.nms_thresh, cfg.use_graph = kw["conf_thresh"], kw["nms_thresh"], 1 if kw["use_graph"] else 0
         cfg.debug_tensors, cfg.precision = (1 if kw["debug_tensors"] else 0), kw["precision"]
+        cfg.fp8_f16_layers, cfg.fp8_per_tensor = kw["fp8_f16_layers"], (1 if kw["fp8_per_tensor"] else 0)
         if kw["tune"]:
             cfg.tune = Tuning.of(**kw["tune"])
         devs = (C.c_int32 * len(devices))(*devices)
