@@ -68,7 +68,10 @@ __global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
         int base = 0;
         if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&p.cls_count[list], __popcll(mask));
         base = __shfl(base, __ffsll((long long)mask) - 1);
-        if (hit) p.cand[(long long)list * p.P + base + __popcll(mask & lt)] = make_uint2(__float_as_uint(pc), (unsigned)pr);
+        // (a list holds at most P entries - every prior once. det_class_nms leaves each counter at zero for the next step; should a step
+        // ever be abandoned between this kernel and that one, the stale count must not carry the store past the list: ADVICE r3)
+        const int slot = base + __popcll(mask & lt);
+        if (hit && slot < p.P) p.cand[(long long)list * p.P + slot] = make_uint2(__float_as_uint(pc), (unsigned)pr);
     }
 }
 
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(192) void det_softmax_cand_c(const DetectParams p) 
         int base = 0;
         if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&p.cls_count[list], __popcll(mask));
         base = __shfl(base, __ffsll((long long)mask) - 1);
-        if (hit) p.cand[(long long)list * p.P + base + __popcll(mask & lt)] = make_uint2(__float_as_uint(pc), (unsigned)pr);
+        // (a list holds at most P entries - every prior once. det_class_nms leaves each counter at zero for the next step; should a step
+        // ever be abandoned between this kernel and that one, the stale count must not carry the store past the list: ADVICE r3)
+        const int slot = base + __popcll(mask & lt);
+        if (hit && slot < p.P) p.cand[(long long)list * p.P + slot] = make_uint2(__float_as_uint(pc), (unsigned)pr);
     }
 }
 

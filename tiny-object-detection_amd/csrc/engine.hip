@@ -2012,12 +2012,17 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     // pipelines its chunks and beats a single-threaded memcpy into staging. The caller's buffer is free again on return either way.
     if (kind == hipMemcpyHostToDevice && bytes <= yh_engine::kStageBytes) {
         const int k = h->stage_idx ^= 1;
-        if (!h->stage[k]) {
-            HIPCHK(h, hipHostMalloc((void**)&h->stage[k], yh_engine::kStageBytes, hipHostMallocDefault));
-            HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
-        } else {
-            HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this staging buffer has finished
+        if (!h->stage[0]) {
+            // BOTH staging buffers at the first host input (round 4): allocated one call apart, the second 4 MB pinned allocation -
+            // milliseconds - fell into whatever the caller was timing after its warm-up call (bench.py's batch-1 pinned-source figure
+            // read 0.80-0.90 of the resident rate for that reason alone, and below the pageable one measured after it)
+            for (int j = 0; j < 2; ++j) {
+                HIPCHK(h, hipHostMalloc((void**)&h->stage[j], yh_engine::kStageBytes, hipHostMallocDefault));
+                HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[j], hipEventDisableTiming));
+                HIPCHK(h, hipEventRecord(h->stage_ev[j], h->copy));
+            }
         }
+        HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this staging buffer has finished
         memcpy(h->stage[k], src, bytes);
         HIPCHK(h, hipMemcpyAsync(dst, h->stage[k], bytes, hipMemcpyHostToDevice, h->copy));
         HIPCHK(h, hipEventRecord(h->stage_ev[k], h->copy));
@@ -2511,7 +2516,11 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
         for (int i = 0; i < nl; ++i) { float t = 0; hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]); acc[i] += t; }
     }
     for (auto& e : ev) hipEventDestroy(e);
-    if (rc) return rc;
+    if (rc) {   // a pass that stopped between the tail's K1 and K2 leaves candidate counts behind: clear them as run()'s error path does
+        hipStreamSynchronize(h->stream); hipStreamSynchronize(h->side);
+        hipMemset(h->det.cls_count, 0, sizeof(int) * (size_t)h->cfg.max_batch * (h->C - 1));
+        return rc;
+    }
     h->prof_labels.assign(nl, std::string());
     for (int i = 0; i < nl; ++i) {
         const ProfEntry& pe = ent[i];

@@ -91,9 +91,21 @@ struct yh_group {
 
 extern "C" {
 
+// The caller's current HIP device is the caller's: every engine entry point binds its handle's device on the calling thread
+// (include/yolact_hip.h), and a group spans several, so the group's entry points put the caller's device back before they return
+// (a torch host that keeps allocating after yh_group_sync must not land on another GPU: ADVICE r3).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) hipSetDevice(dev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 const char* yh_group_last_error(const yh_group* g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
 
 int yh_group_create(const yh_config* cfg, const int32_t* devices, int32_t n, yh_group** out) {
+    DeviceGuard restore_callers_device;
     if (!cfg || !devices || !out || n < 1 || n > 64) { g_group_create_error = "bad argument (1..64 members)"; return YH_EINVAL; }
     *out = nullptr;
     yh_group* g = new yh_group();
@@ -120,6 +132,7 @@ int yh_group_create(const yh_config* cfg, const int32_t* devices, int32_t n, yh_
 }
 
 void yh_group_destroy(yh_group* g) {
+    DeviceGuard restore_callers_device;
     if (!g) return;
     for (Worker* w : g->workers) { w->stop(); delete w; }
     for (yh_engine* e : g->eng) yh_destroy(e);
@@ -136,6 +149,7 @@ const char* yh_group_weights_replication(const yh_group* g) { return g ? g->repl
 // GPU) - the form a one-GPU box can run. If librccl cannot be used, every member on another device receives the blob through
 // the host (one D2H + one H2D per member) and the returned string says so.
 int yh_group_replicate_weights(yh_group* g) {
+    DeviceGuard restore_callers_device;
     if (!g) return YH_EINVAL;
     const int n = (int)g->eng.size();
     const size_t nbytes = yh_weights_nbytes(g->eng[0]);
@@ -178,6 +192,7 @@ int yh_group_replicate_weights(yh_group* g) {
 }
 
 int yh_group_load_weights_host(yh_group* g, const void* blob_host, size_t nbytes) {
+    DeviceGuard restore_callers_device;
     if (!g || !blob_host) return YH_EINVAL;
     const int rc = yh_load_weights_host(g->eng[0], blob_host, nbytes);
     if (rc) return g->member_fail(0, rc);
@@ -187,6 +202,7 @@ int yh_group_load_weights_host(yh_group* g, const void* blob_host, size_t nbytes
 // fp8 precision: member 0 calibrates on the frames last set on it; every member then runs with member 0's scales (frames of
 // one camera stream share a calibration; per-member calibration would make a frame's result depend on which GPU it went to).
 int yh_group_fp8_calibrate(yh_group* g) {
+    DeviceGuard restore_callers_device;
     if (!g) return YH_EINVAL;
     int rc = yh_fp8_calibrate(g->eng[0]);
     if (rc) return g->member_fail(0, rc);
@@ -229,6 +245,7 @@ static int run_members(yh_group* g, const std::function<int(int)>& job) {
 // the member's copy stream underneath its previous step) and enqueues yh_evaluate (with_tail = 1) or yh_invoke. Returns when
 // every member has ENQUEUED its step (the caller's frames are free again); the GPUs run on. n_frames <= members * max_batch.
 int yh_group_evaluate(yh_group* g, const uint8_t* frames_host, int32_t n_frames, int32_t with_tail) {
+    DeviceGuard restore_callers_device;
     if (!g || !frames_host) return YH_EINVAL;
     const int m = (int)g->eng.size();
     if (n_frames < 1 || (long long)n_frames > (long long)m * g->max_batch) return g->fail(YH_EINVAL, "n_frames must be 1 .. members * max_batch");
@@ -244,6 +261,7 @@ int yh_group_evaluate(yh_group* g, const uint8_t* frames_host, int32_t n_frames,
 // The same with frames already resident on each member's OWN device: frames_dev[i] -> counts[i] frames (0 = the member sits
 // this step out). The global frame index runs over the members in order.
 int yh_group_evaluate_device(yh_group* g, const uint8_t* const* frames_dev, const int32_t* counts, int32_t with_tail) {
+    DeviceGuard restore_callers_device;
     if (!g || !frames_dev || !counts) return YH_EINVAL;
     const int m = (int)g->eng.size();
     int total = 0;
@@ -264,6 +282,7 @@ int yh_group_evaluate_device(yh_group* g, const uint8_t* const* frames_dev, cons
 }
 
 int yh_group_sync(yh_group* g) {
+    DeviceGuard restore_callers_device;
     if (!g) return YH_EINVAL;
     for (size_t i = 0; i < g->eng.size(); ++i) {
         const int rc = yh_sync(g->eng[i]);
@@ -285,6 +304,7 @@ int yh_group_frame_owner(const yh_group* g, int32_t frame, int32_t* member, int3
 }
 
 int yh_group_read_detections(yh_group* g, int32_t frame, int32_t* count, yh_detection* dets, int32_t dets_capacity, uint8_t* masks, size_t masks_capacity) {
+    DeviceGuard restore_callers_device;
     if (!g || !count) return YH_EINVAL;
     int32_t mem = 0, loc = 0;
     if (yh_group_frame_owner(g, frame, &mem, &loc) != YH_OK) return g->fail(YH_EINVAL, "frame out of range of the last yh_group_evaluate");
