@@ -117,8 +117,10 @@ typedef struct yh_tuning {
     int32_t xn_tm;           /* layer 3's expand + next-reduce launch, pixel tile: -1 (default) 64-pixel tiles for about one round of
                               * workgroups (bneck_xn_f16), else separate launches; 64 / 128: that form wherever the launch is eligible
                               * (128: bneck_xn128_f16, bit-identical, measured no faster than the separate launches at batch 64) */
-    int32_t slabin;          /* a split-K convolution's partial slabs summed by the CONSUMER's loader instead of a reduce launch
-                              * (batch 1-2: 1, default); 0: splitk_reduce_f16 launches */
+    int32_t slabin;          /* reserved (-1) */
+    int32_t tfl_fuse;        /* TFLite path: 1 (default) element-wise operators (QUANTIZE / RELU / RELU6 / TANH / ADD), PAD and contiguous
+                              * CONCATENATION parts folded into the launch of the convolution / resize that produces their operand -
+                              * same bytes, fewer launches; 0: one launch per operator, every tensor materialised (the checker) */
 } yh_tuning;
 
 typedef struct yh_config {
@@ -383,6 +385,8 @@ int yh_tfl_set_input(yh_tfl* h, const void* data, size_t nbytes);              /
 int yh_tfl_invoke(yh_tfl* h);                                                  /* interpreter.invoke(), :163 */
 int yh_tfl_output_read(yh_tfl* h, int32_t i, void* dst, size_t nbytes);        /* tensor_data::<u8|f32>, :173,:180 */
 int yh_tfl_tensor_count(const yh_tfl* h);
+/* Kernel launches per invoke of the prepared plan; how many are CONV_2D and how many of those run on the int8 matrix pipes. */
+int yh_tfl_plan_info(const yh_tfl* h, int32_t* launches, int32_t* conv_launches, int32_t* conv_mfma_launches);
 int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes);   /* test hook: any tensor by index */
 /* Yolact::classify (src/yolact.rs:192-234) with this model in the middle: two S x S tiles, one
  * invoke each, output 4 dequantised (:177) and post-processed (:90-131), all on device. */

@@ -13,10 +13,10 @@ import tfl_models as M
 pytestmark = pytest.mark.gpu
 
 
-def _run_both(model, x):
+def _run_both(model, x, tune=None):
     import tfl_oracle as O
     import yolact_amd as ya
-    eng = ya.TfliteEngine(B.serialize(model))
+    eng = ya.TfliteEngine(B.serialize(model), tune=tune)
     eng.set_input(x)
     eng.invoke()
     val = O.run_model(model, {model.inputs[0]: x})
@@ -62,12 +62,73 @@ def test_known_answers_dequantize_and_saturation(built):
     eng.close()
 
 
+def _surviving(eng, model, val, ya):
+    """Every tensor the plan still writes == the oracle; returns how many are folded away (reading one says so: YH_ESTATE)."""
+    gone = 0
+    for i in sorted({o for op in model.ops for o in op.outputs}):
+        t = model.tensors[i]
+        try:
+            got = eng.tensor(i, t.shape, B.NP_TYPE[t.dtype])
+        except ya.YhError as e:
+            assert e.code == ya.capi.ESTATE and "folded" in str(e), (i, t.name, str(e))
+            gone += 1
+            continue
+        assert np.array_equal(got, val[i]), (i, t.name)
+    return gone
+
+
+def test_operator_fusion_keeps_every_surviving_tensor_bit_exact(built):
+    """yh_tuning.tfl_fuse (default 1): QUANTIZE / RELU / RELU6 / TANH / ADD folded into the epilogue of the
+    convolution or resize that produces their operand, PAD into the convolution behind it, CONCATENATION parts written in place.
+    Bit-exactness against the numpy oracle on every tensor the fused plan still writes (the 40-op graph: conv -> ADD -> RELU,
+    resize -> nothing (its ADD's other producer runs later), conv -> TANH with two readers, conv -> QUANTIZE -> RESHAPE -> output;
+    the 136-op stand-in: 9 residual ADDs, 2 FPN ADDs, 2 PADs, 5 TANH + 16 QUANTIZE chains into 3 CONCATENATIONs) and equality with
+    the unfused plan (tfl_fuse = 0, the checker) on every output; launch counts from yh_tfl_plan_info."""
+    import yolact_amd as ya
+    rng = np.random.default_rng(7)
+    small = M.mobilenet_like(rng, S=64, C=6)
+    x = rng.integers(0, 256, (1, 64, 64, 3), dtype=np.uint8)
+    eng, val, outs = _run_both(small, x)
+    gone = _surviving(eng, small, val, ya)
+    assert gone >= 4, gone                                # padded, p3sum, the lateral conv's own output, conf / conf_q ...
+    for k, o in enumerate(small.outputs):
+        assert np.array_equal(outs[k], val[o]), small.tensors[o].name
+    eng.close()
+    rng = np.random.default_rng(31)
+    big = M.mobilenetv2_yolact(rng)
+    blob = bytes(B.serialize(big))
+    x = rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8)
+    import tfl_oracle as TO
+    vals = [TO.run_model(big, {big.inputs[0]: x[i:i + 1]}) for i in range(2)]
+    fused, plain = ya.TfliteEngine(blob), ya.TfliteEngine(blob, tune=dict(tfl_fuse=0))
+    pf, pp = fused.plan_summary(), plain.plan_summary()
+    print("fused plan:", pf, " unfused:", pp)
+    assert pp["launches_per_invoke"] >= 130 and pf["launches_per_invoke"] <= 85, (pf, pp)
+    assert pf["conv2d_launches"] == pp["conv2d_launches"] == 64
+    for e in (fused, plain):
+        e.set_batch(2); e.set_input(x); e.invoke()
+    for k, o in enumerate(big.outputs):
+        a, b = fused.output(k), plain.output(k)
+        assert np.array_equal(a, b), big.tensors[o].name
+        for i in range(2):
+            assert np.array_equal(a[i], np.asarray(vals[i][o]).reshape(a[i].shape)), (big.tensors[o].name, i)
+    fused.set_batch(1); fused.set_input(x[:1]); fused.invoke()
+    gone = _surviving(fused, big, vals[0], ya)
+    assert gone >= 45, gone                               # 9 + 2 ADD operands, 2 padded, 21 TANH / QUANTIZE inputs, 15 concat parts ...
+    frame = (rng.integers(0, 256, (480, 640, 3), dtype=np.uint32) * np.array([1 << 24, 1 << 16, 1 << 8], np.uint32)).sum(-1).astype(np.uint32).reshape(-1)
+    fa, fb = frame.copy(), frame.copy()
+    fused.classify_frame(fa, 640, 480, ya.COMPAT_SANE)
+    plain.classify_frame(fb, 640, 480, ya.COMPAT_SANE)
+    assert np.array_equal(fa, fb)
+    fused.close(); plain.close()
+
+
 def test_mobilenet_like_graph_every_tensor(built):
-    """Every activation of a 40-op MobileNetV2-FPN-shaped graph, not only the outputs."""
+    """Every activation of a 40-op MobileNetV2-FPN-shaped graph, not only the outputs (one launch per operator: tfl_fuse = 0)."""
     rng = np.random.default_rng(7)
     model = M.mobilenet_like(rng, S=64, C=6)
     x = rng.integers(0, 256, (1, 64, 64, 3), dtype=np.uint8)
-    eng, val, outs = _run_both(model, x)
+    eng, val, outs = _run_both(model, x, tune=dict(tfl_fuse=0))
     assert eng.output_count() == 5
     info = eng.output_info(4)
     assert info["dims"] == (1, 64, 6) and info["kind"] == 3 and info["scale"] == 0.0078125 and info["zero_point"] == 128
@@ -90,14 +151,18 @@ def test_full_size_mobilenetv2_yolact_graph(built, seed):
     rng = np.random.default_rng(seed)
     model = M.mobilenetv2_yolact(rng)
     x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
-    eng, val, outs = _run_both(model, x)
+    eng, val, outs = _run_both(model, x, tune=dict(tfl_fuse=seed != 0))   # (one seed per plan: fused / one launch per operator)
     assert eng.output_count() == 5 and eng.output_info(4)["dims"] == (1, 784, 81)
     for k, o in enumerate(model.outputs):
         assert np.array_equal(outs[k], val[o]), model.tensors[o].name
+    import yolact_amd as ya
     written = sorted({o for op in model.ops for o in op.outputs})
     for i in written[::7]:
         t = model.tensors[i]
-        assert np.array_equal(eng.tensor(i, t.shape, B.NP_TYPE[t.dtype]), val[i]), (i, t.name)
+        try:
+            assert np.array_equal(eng.tensor(i, t.shape, B.NP_TYPE[t.dtype]), val[i]), (i, t.name)
+        except ya.YhError as e:
+            assert seed != 0 and e.code == ya.capi.ESTATE   # folded into its producer's launch (fused plan only)
     eng.invoke()
     for k, o in enumerate(model.outputs):
         assert np.array_equal(eng.output(k), outs[k])
@@ -226,7 +291,7 @@ def test_batch_plan_two_tiles_in_one_invoke_equals_two_invokes(built, graph):
     rng = np.random.default_rng(23)
     model = M.mobilenetv2_yolact(rng)
     x2 = rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8)
-    eng = ya.TfliteEngine(B.serialize(model), tune=dict(tfl_graph=graph))
+    eng = ya.TfliteEngine(B.serialize(model), tune=dict(tfl_graph=graph, tfl_fuse=0))
     eng.set_batch(2)
     eng.set_input(x2)
     eng.invoke()

@@ -43,6 +43,38 @@ __device__ __forceinline__ int q_mbqm(int x, int m, int shift) {
 }
 __device__ __forceinline__ int q_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Operators folded into their producer at plan time (round 4, yh_tuning.tfl_fuse): the producer computes its own uint8 output
+// value exactly as TFLite does - in a register - and the element-wise operators that consumed it (QUANTIZE / RELU / RELU6 as a
+// requantisation, TANH as its 256-entry table, ADD with its other operand read from memory) run on that value before the one
+// store: the same integers in the same order, no intermediate tensor, no launch. A CONCATENATION part with the output's own
+// quantisation is written by its producer straight into the concatenated tensor, a PAD in front of a convolution becomes that
+// convolution's padding (a padded tap holds the zero point: (x - zx) = 0, the tap TFLite's kernels skip).
+struct PostStep { int kind; int zi, zo, m, s, lo, hi; const uint8_t* lut; };   // 1 requantise, 2 table, 3 the ADD below
+struct PostOps {
+    int n;
+    PostStep st[3];
+    const uint8_t* other; long long other_s;    // ADD: the other operand (same shape), bytes per image
+    int q_is_a, za, zb, m1, s1, m2, s2, mo, so, azo, alo, ahi;
+};
+__device__ __forceinline__ int apply_post(const PostOps& po, int q, long long img, long long elem) {
+    // (compile-time step indices: a run-time index into the kernel-argument block makes the compiler copy the whole block to
+    // scratch - 344 bytes of private memory per lane in every convolution kernel, +45 % per invoke when first measured)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i >= po.n) break;
+        const PostStep& t = po.st[i];
+        if (t.kind == 1) q = q_clamp(q_mbqm(q - t.zi, t.m, t.s) + t.zo, t.lo, t.hi);
+        else if (t.kind == 2) q = t.lut[q];
+        else {
+            const int o = po.other[img * po.other_s + elem];
+            const int a = po.q_is_a ? q : o, b = po.q_is_a ? o : q;
+            const int v1 = q_mbqm((a - po.za) * (1 << 20), po.m1, po.s1), v2 = q_mbqm((b - po.zb) * (1 << 20), po.m2, po.s2);
+            q = q_clamp(q_mbqm(v1 + v2, po.mo, po.so) + po.azo, po.alo, po.ahi);
+        }
+    }
+    return q;
+}
+
 struct ConvQ {
     const uint8_t *x, *w; const int* bias; uint8_t* y;
     int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, dm;
@@ -50,12 +82,14 @@ struct ConvQ {
     const int* wsum;   // [Co][kh*kw]: sum of the raw weight bytes of one tap (dot-product kernel), or nullptr
     // batch plan (yh_tfl_set_batch): the grid's last used dimension is the image; activations are image-major
     long long xs, ys;  // bytes per image of x / y
+    PostOps po;
 };
 
-__global__ __launch_bounds__(256) void tfl_conv_u8(ConvQ p) {
+__global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
-    p.x += blockIdx.y * p.xs; p.y += blockIdx.y * p.ys;
+    const uint8_t* const px = p.x + blockIdx.y * p.xs;
+    uint8_t* const py = p.y + blockIdx.y * p.ys;
     const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo;
     int acc = 0;
     for (int r = 0; r < p.kh; ++r) {
@@ -64,13 +98,13 @@ __global__ __launch_bounds__(256) void tfl_conv_u8(ConvQ p) {
         for (int s = 0; s < p.kw; ++s) {
             const int ix = ox * p.sw - p.pw + s * p.dw;
             if ((unsigned)ix >= (unsigned)p.W) continue;
-            const uint8_t* xp = p.x + ((size_t)iy * p.W + ix) * p.Ci;
+            const uint8_t* xp = px + ((size_t)iy * p.W + ix) * p.Ci;
             const uint8_t* wp = p.w + (((size_t)oc * p.kh + r) * p.kw + s) * p.Ci;
             for (int c = 0; c < p.Ci; ++c) acc += ((int)xp[c] - p.zx) * ((int)wp[c] - p.zw);
         }
     }
     acc += p.bias ? p.bias[oc] : 0;
-    p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
+    py[t] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.y, t);
 }
 
 // Same arithmetic, four MACs per instruction: for Ci % 4 == 0 the sum over the valid taps of
@@ -83,9 +117,10 @@ __global__ __launch_bounds__(256) void tfl_conv_u8(ConvQ p) {
 // channels (the model's layers are small: 28 x 28 pixels x 128 channels is 13 x 16 workgroups, and
 // the serial chain per lane is what takes the time) and wave 0 adds the partial sums from LDS.
 template <int KS>
-__global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(ConvQ p) {
+__global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(const ConvQ p) {
     __shared__ unsigned part[KS > 1 ? (KS - 1) * 9 * 64 : 1];
-    p.x += blockIdx.z * p.xs; p.y += blockIdx.z * p.ys;
+    const uint8_t* const px = p.x + blockIdx.z * p.xs;
+    uint8_t* const py = p.y + blockIdx.z * p.ys;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int pix = blockIdx.x * 64 + lane, oc0 = blockIdx.y * 8;
     const bool live = pix < p.Ho * p.Wo;
@@ -99,7 +134,7 @@ __global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(ConvQ p) {
         for (int s = 0; s < p.kw; ++s) {
             const int ix = ox * p.sw - p.pw + s * p.dw, tap = r * p.kw + s;
             if (!live || (unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
-            const unsigned* xp = (const unsigned*)(p.x + ((size_t)iy * p.W + ix) * p.Ci);
+            const unsigned* xp = (const unsigned*)(px + ((size_t)iy * p.W + ix) * p.Ci);
             for (int c = c_lo; c < c_hi; ++c) {
                 const unsigned xv = xp[c];
                 sx = __builtin_amdgcn_udot4(xv, 0x01010101u, sx, false);
@@ -138,7 +173,7 @@ __global__ __launch_bounds__(64 * KS) void tfl_conv_u8_dot(ConvQ p) {
         const int oc = oc0 + j;
         if (oc < p.Co) {
             const int a = (int)acc[j] + base - p.zx * ws[j] + (p.bias ? p.bias[oc] : 0);
-            p.y[(size_t)pix * p.Co + oc] = (uint8_t)q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi);
+            py[(size_t)pix * p.Co + oc] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.z, (long long)pix * p.Co + oc);
         }
     }
 }
@@ -156,8 +191,40 @@ struct ConvI8 {
     int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw;
     int zx, zw, zo, mult, shift, lo, hi, K, M;
     long long xs, ys;
+    PostOps po;
 };
 typedef int v4i __attribute__((ext_vector_type(4)));
+// Epilogue of the int8 MFMA convolutions: lane = pixel (wm, j, l15), channels (wc, i, 4 lg + e) [C/D layout of the 16 x 16 MFMA:
+// column = lane & 15, rows 4 (lane >> 4) + e]; sx[j] = sum of the raw input bytes over the whole K of pixel (wm, j, l15).
+__device__ __forceinline__ void conv_i8_epilogue(const ConvI8& p, const v4i (&acc)[2][2], const unsigned (&sx)[2], int m0, int ch0, int wc, int wm, int l15, int lg, int HoWo) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mo = m0 + wm * 32 + j * 16 + l15;
+        if (mo >= p.M) continue;
+        const int im = mo / HoWo, px = mo - im * HoWo;
+        uint8_t* yrow = p.y + (long long)im * p.ys + (size_t)px * p.Co;
+        const int xterm = (128 - p.zw) * ((int)sx[j] - 128 * p.K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = ch0 + wc * 32 + i * 16 + 4 * lg;
+            if (ch >= p.Co) continue;
+            unsigned packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = acc[i][j][e] + xterm + p.cterm[ch + e];   // (cterm is padded to CoPad)
+                const unsigned q = (unsigned)apply_post(p.po, q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi), im, (long long)px * p.Co + (ch + e < p.Co ? ch + e : 0));
+                packed |= q << (8 * e);
+            }
+            if ((p.Co & 3) == 0 && (((size_t)yrow) & 3) == 0) *(unsigned*)(yrow + ch) = packed;   // (a CONCATENATION part may start at any byte)
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ch + e < p.Co) yrow[ch + e] = (uint8_t)(packed >> (8 * e));
+            }
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
     __shared__ __attribute__((aligned(16))) char lds[2][8192];   // [stage][A 64 rows x 64 B | B 64 rows x 64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -173,18 +240,34 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
     const unsigned zx4 = (unsigned)p.zx * 0x01010101u;
     const int lds_w = lrow * 64 + ((lchunk ^ ((lrow >> 2) & 3)) << 4);
     const int cchunks = p.Ci >> 6, nsteps = p.kh * p.kw * cchunks;
-    uint4 ra, rb;
-    auto fetch = [&](int step) {
-        const int tap = step / cchunks, cc = step - tap * cchunks, r = tap / p.kw, s_ = tap - r * p.kw;
-        ra = *(const uint4*)(wrow + (size_t)step * 64);        // K index = tap * Ci + cc * 64 = step * 64
-        const int iy = oy * p.sh - p.ph + r * p.dh, ix = ox * p.sw - p.pw + s_ * p.dw;
-        if (mlive && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            rb = *(const uint4*)(ximg + ((size_t)iy * p.W + ix) * p.Ci + cc * 64 + lchunk * 16);
-        else rb = make_uint4(zx4, zx4, zx4, zx4);              // padded tap (and rows past M): x = zx contributes (x - zx) = 0
+    // Register ring: the tiles of the next THREE k-steps are in flight while one is computed. The layers are small (50-200
+    // workgroups of 2-18 k-steps) and every step used to wait one L2 round trip for the single tile it had prefetched: the kernel
+    // was bound by steps x latency (12 us per launch, 46 launches = 0.67 of a 0.97 ms invoke). The ring is rotated by register
+    // moves (a move waits for the load that fills its source, so four slots give three steps of distance).
+    struct Tile { uint4 a, b; };
+    // position of the NEXT tile to fetch along K, advanced incrementally (k order: tap outer, 64-channel chunk inner): the step
+    // index is wave-uniform, and two integer divisions per k-step were a third of a step's instructions on a wave that has its
+    // SIMD to itself (one workgroup of four waves per CU: nothing else hides them)
+    int f_r = 0, f_s = 0, f_cc = 0, f_step = 0;
+    const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
+    const uint8_t* const xlane = ximg + lchunk * 16;
+    auto fetch = [&]() {
+        Tile t;
+        t.a = *(const uint4*)(wrow + (size_t)f_step * 64);       // K index = tap * Ci + cc * 64 = step * 64
+        const int iy = iy0 + f_r * p.dh, ix = ix0 + f_s * p.dw;
+        const bool in = mlive && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        // padded tap (and rows past M): x = zx contributes (x - zx) = 0. (The address is clamped into the image, the value selected.)
+        const uint4 v = *(const uint4*)(xlane + (unsigned)(((in ? iy : 0) * p.W + (in ? ix : 0)) * p.Ci + f_cc * 64));
+        t.b = in ? v : make_uint4(zx4, zx4, zx4, zx4);
+        if (f_step + 1 < nsteps) {                                // (past the end: the last tile again, never used)
+            ++f_step;
+            if (++f_cc == cchunks) { f_cc = 0; if (++f_s == p.kw) { f_s = 0; ++f_r; } }
+        }
+        return t;
     };
-    auto stash = [&](int st) {
-        *(uint4*)(lds[st] + lds_w) = ra;
-        *(uint4*)(lds[st] + 4096 + lds_w) = rb;
+    auto stash = [&](int st, const Tile& t) {
+        *(uint4*)(lds[st] + lds_w) = t.a;
+        *(uint4*)(lds[st] + 4096 + lds_w) = t.b;
     };
     const int wc = wave >> 1, wm = wave & 1;
     v4i acc[2][2];
@@ -193,12 +276,13 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = v4i{ 0, 0, 0, 0 };
-    fetch(0);
-    stash(0);
+    Tile t0 = fetch(), t1 = fetch(), t2 = fetch(), t3 = fetch();
+    stash(0, t0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int st = step & 1;
-        if (step + 1 < nsteps) fetch(step + 1);                // in flight under this step's MFMAs
+        // t1, t2, t3 = tiles step + 1 .. step + 3 (in flight); the slot of the tile now in LDS takes tile step + 4
+        t0 = fetch();
         v4i fa[2], fb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -219,10 +303,9 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (step + 1 < nsteps) {
-            stash(st ^ 1);                                     // (the other stage was last read one step ago, behind a barrier)
-            __syncthreads();
-        }
+        stash(st ^ 1, t1);                                     // (the other stage was last read one step ago, behind a barrier; after the last step: unused)
+        __syncthreads();
+        t1 = t2; t2 = t3; t3 = t0;
     }
     // sum x over the whole K of this lane's pixel: the four lane groups hold the four 16-byte quarters of every k-step
 #pragma unroll
@@ -230,38 +313,20 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
         sx[j] += __shfl_xor(sx[j], 16);
         sx[j] += __shfl_xor(sx[j], 32);
     }
-    // lane: pixel (wm, j, l15), channels (wc, i, 4 lg + e)   [C/D layout of the 16 x 16 MFMA: column = lane & 15, rows 4 (lane >> 4) + e]
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int mo = m0 + wm * 32 + j * 16 + l15;
-        if (mo >= p.M) continue;
-        const int im = mo / HoWo, px = mo - im * HoWo;
-        uint8_t* yrow = p.y + (long long)im * p.ys + (size_t)px * p.Co;
-        const int xterm = (128 - p.zw) * ((int)sx[j] - 128 * p.K);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = ch0 + wc * 32 + i * 16 + 4 * lg;
-            if (ch >= p.Co) continue;
-            unsigned packed = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int a = acc[i][j][e] + xterm + p.cterm[ch + e];   // (cterm is padded to CoPad)
-                const unsigned q = (unsigned)q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi);
-                packed |= q << (8 * e);
-            }
-            if ((p.Co & 3) == 0) *(unsigned*)(yrow + ch) = packed;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (ch + e < p.Co) yrow[ch + e] = (uint8_t)(packed >> (8 * e));
-            }
-        }
-    }
+    conv_i8_epilogue(p, acc, sx, m0, ch0, wc, wm, l15, lg, HoWo);
 }
 
-__global__ __launch_bounds__(256) void tfl_dwconv_u8(ConvQ p) {
+// (Round 4 also built the same convolution with its K split over the four waves of the workgroup - every wave the whole 64 x 64
+// tile for a quarter of the k-steps, partial tiles added through LDS atomics: bit-identical, and SLOWER everywhere (18 k-steps: 13 ->
+// 16-20 us, 4 k-steps: 5.3 -> 9.5 us). A launch costs 6.4 us + 0.36 us per k-step whatever its pixel count (tools/study/
+// tfl_conv_steps.py), and that per-step cost is the wave's own instruction issue - 88 instructions - not a latency the split
+// could overlap: four times the work per wave and step took four times as long. Removed.)
+
+__global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.Co) return;
-    p.x += blockIdx.y * p.xs; p.y += blockIdx.y * p.ys;
+    const uint8_t* const px = p.x + blockIdx.y * p.xs;
+    uint8_t* const py = p.y + blockIdx.y * p.ys;
     const int oc = t % p.Co, r0 = t / p.Co, ox = r0 % p.Wo, oy = r0 / p.Wo, ic = oc / p.dm;
     int acc = 0;
     for (int r = 0; r < p.kh; ++r) {
@@ -270,11 +335,11 @@ __global__ __launch_bounds__(256) void tfl_dwconv_u8(ConvQ p) {
         for (int s = 0; s < p.kw; ++s) {
             const int ix = ox * p.sw - p.pw + s * p.dw;
             if ((unsigned)ix >= (unsigned)p.W) continue;
-            acc += ((int)p.x[((size_t)iy * p.W + ix) * p.Ci + ic] - p.zx) * ((int)p.w[((size_t)r * p.kw + s) * p.Co + oc] - p.zw);
+            acc += ((int)px[((size_t)iy * p.W + ix) * p.Ci + ic] - p.zx) * ((int)p.w[((size_t)r * p.kw + s) * p.Co + oc] - p.zw);
         }
     }
     acc += p.bias ? p.bias[oc] : 0;
-    p.y[t] = (uint8_t)q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi);
+    py[t] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.y, t);
 }
 
 // RESHAPE: a plain device copy as a kernel (a memcpy NODE in the captured plan crashed rocprofv3's
@@ -327,11 +392,12 @@ __global__ __launch_bounds__(256) void tfl_pad_u8(const PadQ p) {
     for (int d = 0; d < 4; ++d) in = in && (unsigned)c[d] < (unsigned)p.id[d];
     p.y[t] = in ? p.x[(((long long)c[0] * p.id[1] + c[1]) * p.id[2] + c[2]) * p.id[3] + c[3]] : (uint8_t)p.fill;
 }
-struct ResizeQ { const uint8_t* x; uint8_t* y; int H, W, C, Ho, Wo; float hs, ws; int half_pixel; };
-__global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(ResizeQ p) {
+struct ResizeQ { const uint8_t* x; uint8_t* y; int H, W, C, Ho, Wo; float hs, ws; int half_pixel; long long ys; PostOps po; };
+__global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(const ResizeQ p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.Ho * p.Wo * p.C) return;
-    p.x += (size_t)blockIdx.y * p.H * p.W * p.C; p.y += (size_t)blockIdx.y * p.Ho * p.Wo * p.C;   // (batch plan: image-major)
+    const uint8_t* const px = p.x + (size_t)blockIdx.y * p.H * p.W * p.C;   // (batch plan: image-major)
+    uint8_t* const py = p.y + blockIdx.y * p.ys;
     const int c = t % p.C, r0 = t / p.C, ox = r0 % p.Wo, oy = r0 / p.Wo;
     const float iy = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)oy, 0.5f), p.hs), 0.5f) : __fmul_rn((float)oy, p.hs);
     const float ix = p.half_pixel ? __fsub_rn(__fmul_rn(__fadd_rn((float)ox, 0.5f), p.ws), 0.5f) : __fmul_rn((float)ox, p.ws);
@@ -340,13 +406,13 @@ __global__ __launch_bounds__(256) void tfl_resize_bilinear_u8(ResizeQ p) {
     y1 = y1 > p.H - 1 ? p.H - 1 : y1; x1 = x1 > p.W - 1 ? p.W - 1 : x1;
     const float fy = __fsub_rn(iy, (float)y0), fx = __fsub_rn(ix, (float)x0);
     const float gy = __fsub_rn(1.0f, fy), gx = __fsub_rn(1.0f, fx);
-    auto at = [&](int yy, int xx) { return (float)p.x[((size_t)yy * p.W + xx) * p.C + c]; };
+    auto at = [&](int yy, int xx) { return (float)px[((size_t)yy * p.W + xx) * p.C + c]; };
     float v = __fmul_rn(__fmul_rn(at(y0, x0), gy), gx);
     v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y1, x0), fy), gx));
     v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y0, x1), gy), fx));
     v = __fadd_rn(v, __fmul_rn(__fmul_rn(at(y1, x1), fy), fx));
     const float r = floorf(__fadd_rn(v, 0.5f));
-    p.y[t] = (uint8_t)(r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r));
+    py[t] = (uint8_t)apply_post(p.po, r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r), blockIdx.y, t);
 }
 // copy one concat input [outer][inner] into the output at column `off` of rows of `row` elements
 struct CatQ { const uint8_t* x; uint8_t* y; long long outer; int inner, row, off, esz; int rescale; float sc, bias; int zo; };
@@ -391,6 +457,8 @@ void same_pad(int in, int k, int stride, int dil, int* out, int* before) {
 enum PKind { P_CONV, P_DW, P_ADD, P_REQUANT, P_QUANT_F32, P_DEQUANT, P_LUT, P_PAD, P_RESIZE, P_CONCAT, P_COPY, P_CONV_I8 };
 struct Prepared {
     PKind kind;
+    int oi = -1;         // operator index in the model
+    bool dead = false;   // folded into another launch (fuse_plan)
     ConvQ conv; ConvI8 ci8; AddQ add; PadQ pad; ResizeQ rs;
     std::vector<CatQ> cat;
     const void* src = nullptr; void* dst = nullptr; long long n = 0;
@@ -414,6 +482,8 @@ struct yh_tfl {
     int nb = 1;                                  // images of the next invoke (yh_tfl_set_batch)
     bool batch_ok = true;                        // no operator of the model touches the image axis
     hipGraphExec_t gexecs[kMaxBatch] = { nullptr, nullptr };   // the plan per batch size, captured once and replayed (tensor addresses never change)
+    int use_fuse = 1;                 // yh_tuning.tfl_fuse: element-wise operators / PAD / CONCATENATION parts folded into their producers (fuse_plan)
+    std::vector<char> gone;           // tensor i is never written by the fused plan (yh_tfl_tensor_read says so)
     int use_dot = 2, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel where Ci % 64 == 0: default) / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -451,7 +521,8 @@ int prepare(yh_tfl* h) {
     for (size_t oi = 0; oi < m.ops.size(); ++oi) {
         const TflOp& op = m.ops[oi];
         const std::string at = " (operator " + std::to_string(oi) + ")";
-        Prepared pr;
+        Prepared pr = Prepared();   // (value-initialised: the kernel parameter blocks start zeroed - no folded operators)
+        pr.oi = (int)oi;
         auto u8 = [&](int i) { return T(i).type == TFL_U8 && T(i).quant; };
         switch (op.code) {
             case TFL_CONV_2D:
@@ -603,7 +674,7 @@ int prepare(yh_tfl* h) {
                 if (!need(y.shape[1] == q.Ho && y.shape[2] == q.Wo && y.shape[3] == q.C, "resize_bilinear: output shape mismatch" + at)) return YH_EINVAL;
                 q.hs = (op.align_corners && q.Ho > 1) ? (float)(q.H - 1) / (float)(q.Ho - 1) : (float)q.H / (float)q.Ho;
                 q.ws = (op.align_corners && q.Wo > 1) ? (float)(q.W - 1) / (float)(q.Wo - 1) : (float)q.W / (float)q.Wo;
-                q.x = (const uint8_t*)h->tens[op.in[0]]; q.y = (uint8_t*)h->tens[op.out[0]];
+                q.x = (const uint8_t*)h->tens[op.in[0]]; q.y = (uint8_t*)h->tens[op.out[0]]; q.ys = (long long)q.Ho * q.Wo * q.C;
                 pr.kind = P_RESIZE;
                 break;
             }
@@ -661,12 +732,113 @@ int prepare(yh_tfl* h) {
     return YH_OK;
 }
 
+// Plan-time operator fusion (yh_tuning.tfl_fuse, default on). The reference runs 138 of its 141 operators as
+// ONE compiled unit on the EdgeTPU (data/README.md:34-39); one launch per operator made ~70 small kernels at their ~5 us floor
+// 0.35 ms of a 0.9 ms invoke. Folded here, all bit-exact by construction (PostOps above):
+//   * QUANTIZE / RELU / RELU6 (uint8 -> uint8), TANH and ADD into the epilogue of the convolution, depthwise convolution or
+//     RESIZE_BILINEAR that produces their operand last - when that tensor has no other reader and is not a graph output;
+//   * a CONCATENATION part whose quantisation equals the output's and which is one contiguous block per image: its producer
+//     writes straight into the concatenated tensor;
+//   * PAD (height / width only) in front of convolutions: the convolution reads the unpadded tensor with the padding as its own.
+// RESHAPE already shares its input's buffer. Tensors that are no longer written are listed in h->gone.
+void fuse_plan(yh_tfl* h) {
+    const TflModel& m = h->m;
+    const int nt = (int)m.tensors.size(), nops = (int)m.ops.size();
+    std::vector<int> root(nt), plan_of(nops, -1), out_refs(nt, 0), prod(nt, -1);
+    for (int i = 0; i < nt; ++i) root[i] = i;
+    for (const TflOp& op : m.ops)   // (topological order: the input's root is final when its reshape is met)
+        if (op.code == TFL_RESHAPE && !op.in.empty() && h->tens[op.out[0]] == h->tens[op.in[0]]) root[op.out[0]] = root[op.in[0]];
+    for (size_t pi = 0; pi < h->plan.size(); ++pi) plan_of[h->plan[pi].oi] = (int)pi;
+    std::vector<std::vector<int>> cons(nt);
+    for (int oi = 0; oi < nops; ++oi) {
+        if (plan_of[oi] < 0) continue;   // (buffer-sharing RESHAPE: transparent)
+        for (int t : m.ops[oi].in) if (t >= 0 && !m.tensors[t].data) cons[root[t]].push_back(oi);
+        for (int t : m.ops[oi].out) prod[root[t]] = plan_of[oi];
+    }
+    for (int t : m.outputs) ++out_refs[root[t]];
+    auto mark_gone = [&](int r) { for (int t = 0; t < nt; ++t) if (root[t] == r) h->gone[t] = 1; };
+    auto is_conv = [](PKind k) { return k == P_CONV || k == P_CONV_I8 || k == P_DW; };
+    // ---- PAD into the convolutions that read it
+    for (Prepared& pd : h->plan) {
+        if (pd.kind != P_PAD) continue;
+        const PadQ& q = pd.pad;
+        const int r = root[m.ops[pd.oi].out[0]];
+        if (q.before[0] || q.before[3] || q.od[0] != q.id[0] || q.od[3] != q.id[3] || out_refs[r]) continue;
+        bool all = !cons[r].empty();
+        for (int c : cons[r]) all = all && is_conv(h->plan[plan_of[c]].kind) && root[m.ops[c].in[0]] == r;
+        if (!all) continue;
+        for (int c : cons[r]) {
+            Prepared& cv = h->plan[plan_of[c]];
+            ConvQ& k = cv.conv;
+            k.x = q.x; k.H = q.id[1]; k.W = q.id[2]; k.ph += q.before[1]; k.pw += q.before[2]; k.xs = (long long)k.H * k.W * k.Ci;
+            if (cv.kind == P_CONV_I8) { ConvI8& e = cv.ci8; e.x = k.x; e.H = k.H; e.W = k.W; e.ph = k.ph; e.pw = k.pw; e.xs = k.xs; }
+        }
+        pd.dead = true;
+        mark_gone(r);
+    }
+    // ---- element-wise consumers, ADD and contiguous CONCATENATION parts into their producers
+    for (size_t pi = 0; pi < h->plan.size(); ++pi) {
+        Prepared& p = h->plan[pi];
+        if (p.dead || !(is_conv(p.kind) || p.kind == P_RESIZE)) continue;
+        PostOps po;
+        memset(&po, 0, sizeof po);
+        int cur = root[m.ops[p.oi].out[0]];
+        uint8_t* y = nullptr;
+        long long ys = 0;
+        bool has_add = false;
+        while (!out_refs[cur] && cons[cur].size() == 1) {
+            const int c = cons[cur][0], cp = plan_of[c];
+            if (cp <= (int)pi) break;
+            Prepared& q = h->plan[cp];
+            if (q.dead) break;
+            if ((q.kind == P_REQUANT || q.kind == P_LUT) && po.n < 3) {
+                PostStep& t = po.st[po.n++];
+                t.kind = q.kind == P_REQUANT ? 1 : 2;
+                t.zi = q.zi; t.zo = q.zo; t.m = q.m; t.s = q.s; t.lo = q.lo; t.hi = q.hi; t.lut = q.lut;
+            } else if (q.kind == P_ADD && !has_add && po.n < 3) {
+                const int a = root[m.ops[c].in[0]], b = root[m.ops[c].in[1]], other = a == cur ? b : a;
+                // the other operand must be complete when this producer runs: written by an earlier launch (or the graph input / a constant)
+                if (a == b || (prod[other] >= (int)pi) || h->gone[other]) break;
+                po.st[po.n++].kind = 3;
+                has_add = true;
+                po.q_is_a = a == cur;
+                po.other = po.q_is_a ? q.add.b : q.add.a;
+                po.other_s = q.add.n;   // (uint8: elements = bytes per image)
+                po.za = q.add.za; po.zb = q.add.zb; po.m1 = q.add.m1; po.s1 = q.add.s1; po.m2 = q.add.m2; po.s2 = q.add.s2;
+                po.mo = q.add.mo; po.so = q.add.so; po.azo = q.add.zo; po.alo = q.add.lo; po.ahi = q.add.hi;
+            } else if (q.kind == P_CONCAT) {
+                size_t k = 0;
+                for (; k < q.cat.size(); ++k) if (q.cat[k].x == (const uint8_t*)h->tens[cur]) break;
+                if (k == q.cat.size()) break;
+                const CatQ part = q.cat[k];
+                if (part.rescale || part.esz != 1 || part.outer != 1) break;
+                y = part.y + part.off; ys = part.row;
+                q.cat.erase(q.cat.begin() + (long)k);
+                if (q.cat.empty()) q.dead = true;
+                mark_gone(cur);
+                cur = -1;
+                break;
+            } else break;
+            q.dead = true;
+            mark_gone(cur);
+            cur = root[m.ops[c].out[0]];
+        }
+        if (cur >= 0 && cur != root[m.ops[p.oi].out[0]]) { y = (uint8_t*)h->tens[cur]; h->gone[cur] = 0; for (int t = 0; t < nt; ++t) if (root[t] == cur) h->gone[t] = 0; }
+        if (p.kind == P_RESIZE) { p.rs.po = po; if (y) { p.rs.y = y; if (ys) p.rs.ys = ys; } }
+        else {
+            p.conv.po = po; p.ci8.po = po;
+            if (y) { p.conv.y = y; p.ci8.y = y; if (ys) { p.conv.ys = ys; p.ci8.ys = ys; } }
+        }
+    }
+}
+
 int enqueue_plan(yh_tfl* h) {
     hipStream_t s = h->stream;
     const unsigned nb = (unsigned)h->nb;   // images of this invoke: activations are image-major, so element-wise ops just see nb x the elements
     TraceRange tr_all("yh_tfl:plan(enqueue)");
     for (size_t pi = 0; pi < h->plan.size(); ++pi) {
         const Prepared& p = h->plan[pi];
+        if (p.dead) continue;   // folded into another launch (fuse_plan)
         static const char* kind_name[] = { "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RELU/QUANTIZE", "QUANTIZE(f32)", "DEQUANTIZE", "TANH", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE(copy)", "CONV_2D(int8 MFMA)" };
         TraceRange tr(kind_name[p.kind]);   // (roctx: one range per operator, named by its TFLite op; a no-op unless a tracer is attached)
         switch (p.kind) {
@@ -782,6 +954,7 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     h->dev = device;
     if (tune && tune->tfl_dot >= 0) h->use_dot = tune->tfl_dot;
     if (tune && tune->tfl_graph >= 0) h->use_graph = tune->tfl_graph;
+    if (tune && tune->tfl_fuse >= 0) h->use_fuse = tune->tfl_fuse;
     h->file.assign((const uint8_t*)model_bytes, (const uint8_t*)model_bytes + nbytes);
     auto bail = [&](int rc) { g_tfl_create_error = h->err; yh_tfl_destroy(h); return rc; };
     if (!h->m.parse(h->file.data(), h->file.size())) { h->err = "tflite parse: " + h->m.error; return bail(YH_EWEIGHTS); }
@@ -791,7 +964,25 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || hipMalloc(&h->side_word, 16) != hipSuccess) { h->err = "device setup failed"; return bail(YH_EHIP); }
     int rc = prepare(h);
     if (rc) return bail(rc);
+    h->gone.assign(h->m.tensors.size(), 0);
+    if (h->use_fuse) fuse_plan(h);
     *out = h;
+    return YH_OK;
+}
+
+// Launches per invoke of the plan, and how many of them are CONV_2D / of those on the int8 matrix pipes.
+int yh_tfl_plan_info(const yh_tfl* h, int32_t* launches, int32_t* conv_launches, int32_t* conv_mfma_launches) {
+    if (!h) return YH_EINVAL;
+    int n = 0, nc = 0, nm = 0;
+    for (const Prepared& p : h->plan) {
+        if (p.dead) continue;
+        n += p.kind == P_CONCAT ? (int)p.cat.size() : 1;
+        if (p.kind == P_CONV || p.kind == P_CONV_I8) ++nc;
+        if (p.kind == P_CONV_I8) ++nm;
+    }
+    if (launches) *launches = n;
+    if (conv_launches) *conv_launches = nc;
+    if (conv_mfma_launches) *conv_mfma_launches = nm;
     return YH_OK;
 }
 
@@ -855,6 +1046,8 @@ int yh_tfl_invoke(yh_tfl* h) {
 int yh_tfl_tensor_read(yh_tfl* h, int32_t tensor, void* dst, size_t nbytes) {
     if (!h || !dst || tensor < 0 || tensor >= (int)h->m.tensors.size()) return YH_EINVAL;
     const TflTensor& t = h->m.tensors[tensor];
+    if (tensor < (int)h->gone.size() && h->gone[tensor])
+        return h->fail(YH_ESTATE, "tensor '" + t.name + "' is folded into its producer's launch and never written (yh_tuning.tfl_fuse = 0 materialises every tensor)");
     if (nbytes != t.count() * t.elem() * (size_t)(t.data ? 1 : h->nb)) return h->fail(YH_EINVAL, "tensor size mismatch (activations hold yh_tfl_set_batch images)");
     TCHK(h, hipSetDevice(h->dev));
     TCHK(h, hipMemcpyAsync(dst, h->tens[tensor], nbytes, hipMemcpyDeviceToHost, h->stream));

@@ -22,7 +22,7 @@ PRECISION_F16, PRECISION_FP8 = 0, 1
 # yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
 TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
                  "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
-                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "xn_tm", "slabin")
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "xn_tm", "slabin", "tfl_fuse")
 
 
 class Tuning(C.Structure):
@@ -135,6 +135,7 @@ SYMBOLS = [
     ("yh_tfl_invoke", _i, [_vp]),
     ("yh_tfl_output_read", _i, [_vp, _i, _vp, _sz]),
     ("yh_tfl_tensor_count", _i, [_vp]),
+    ("yh_tfl_plan_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("yh_tfl_tensor_read", _i, [_vp, _i, _vp, _sz]),
     ("yh_tfl_classify_frame_u32", _i, [_vp, _vp, _i, _i, _i]),
     ("yh_scene_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
@@ -791,6 +792,12 @@ class TfliteEngine:
         out = np.empty(((nb,) + tuple(info["dims"])) if nb > 1 else info["dims"], _KIND_NP[info["kind"]])
         self._chk(self.L.yh_tfl_output_read(self.h, i, _p(out), out.nbytes))
         return out
+
+    def plan_summary(self):
+        """Launches per invoke of the prepared plan, CONV_2D launches and how many of those run on the int8 matrix pipes."""
+        a, b, c = _i(), _i(), _i()
+        self._chk(self.L.yh_tfl_plan_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(launches_per_invoke=a.value, conv2d_launches=b.value, conv2d_on_int8_mfma=c.value)
 
     def tensor(self, index, shape, dtype):
         nb = getattr(self, "nb", 1)
