@@ -24,6 +24,7 @@ DUAL = "bneck_chain_f16<64,128,next,dual"
 
 
 XN = "bneck_xn_f16"
+XN2_64, XN2_128 = "bneck_xn2_f16<64", "bneck_xn2_f16<128"   # round 4: the pipelined form (tune.xn_pipe = 1): one barrier per chunk, W_a' fragments in registers
 XN128 = "bneck_xn128_f16"   # round 4: the same launch on 128-pixel tiles (tune.xn_tm = 128; not in the default plan)
 
 
@@ -40,6 +41,10 @@ XN128 = "bneck_xn128_f16"   # round 4: the same launch on 128-pixel tiles (tune.
     (3, {"xn_tm": 128}, {XN128, DUAL}, 6, 4, 4),                                                          # the 128-pixel form forced on a full chip: 3 675 pixels = 28 tiles + 91 rows (a last tile whose second row pass is partly past M)
     (1, {"xn_tm": 128}, {XN128}, 6, 4, 4),                                                                # ... 1 225 pixels: a last tile of 73 rows
     (2, {"xn_tm": 64}, {XN}, 6, 4, 4),                                                                    # the 64-pixel form forced outside its window
+    (8, {"xn_pipe": 1}, {XN2_64, DUAL}, 6, 4, 4),                                                         # the pipelined kernel in the 64-pixel form's window (154 tiles of which the last holds 8 rows)
+    (8, {"plan_cus": 32, "xn_tm": 128, "xn_pipe": 1}, {XN2_128, "bneck_chain_f16<128,128"}, 6, 4, 4),    # ... on 128-pixel tiles
+    (3, {"xn_tm": 128, "xn_pipe": 1}, {XN2_128}, 6, 4, 4),                                                # ... 28 tiles + 91 rows
+    (1, {"xn_tm": 64, "xn_pipe": 1}, {XN2_64}, 6, 4, 4),                                                  # ... 19 tiles + 9 rows
 ])
 def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains, nexts, xn):
     import yolact_amd as ya
@@ -88,8 +93,8 @@ def test_chain_layers_against_the_oracle(built, oracle):
         assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()))
     eng.close()
     # layer 3's expand + next-reduce launch in both tile sizes: its two outputs per block against the oracle's forward
-    for tm, sym in ((128, XN128), (64, XN)):
-        eng = ya.Engine(input_size=S, max_batch=2, use_graph=True, tune=dict(xn_tm=tm))
+    for tm, pipe, sym in ((128, 0, XN128), (64, 0, XN), (128, 1, XN2_128 + ">"), (64, 1, XN2_64 + ">")):
+        eng = ya.Engine(input_size=S, max_batch=2, use_graph=True, tune=dict(xn_tm=tm, xn_pipe=pipe))
         eng.load_weights(blob)
         eng.set_input(frames); eng.evaluate()
         assert sum(p["name"].startswith(sym + ":") for p in eng.profile(with_tail=False, reps=1)) == 4
@@ -99,8 +104,8 @@ def test_chain_layers_against_the_oracle(built, oracle):
         eng.close()
 
 
-@pytest.mark.parametrize("xn_tm,sym", [(-1, XN), (128, XN128)])
-def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, sym):
+@pytest.mark.parametrize("xn_tm,pipe,sym", [(-1, 0, XN), (128, 0, XN128), (-1, 1, XN2_64 + ">"), (128, 1, XN2_128 + ">")])
+def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, pipe, sym):
     """configs[4]'s own share (YOLACT-700 R101, fp8 precision, 8 frames per GPU) is where layer 3's expand + next-reduce launch runs
     (242 tiles on 256 CUs), and there its second output feeds an fp8 convolution: a' is written as E4M3 codes by the fused launch.
     Same bytes as the separate launches on every head output and detection."""
@@ -108,7 +113,7 @@ def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, s
     n, s = 8, 700
     frames = np.random.default_rng(21).integers(0, 256, (n, s, s, 3), dtype=np.uint8)
     engs, blob = [], None
-    for tune in ({"xn_tm": xn_tm}, {"chain": 17 + 128}):
+    for tune in ({"xn_tm": xn_tm, "xn_pipe": pipe}, {"chain": 17 + 128}):
         e = ya.Engine(input_size=s, backbone=101, max_batch=n, use_graph=True, precision=ya.PRECISION_FP8, tune=tune or None)
         if blob is None:
             blob = e.generate_weights(seed=1)

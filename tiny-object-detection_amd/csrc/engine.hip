@@ -129,7 +129,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, slabin;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, slabin, xn_pipe;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -142,7 +142,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
-    r.xn_tm = t.xn_tm; r.slabin = d(t.slabin, 1);
+    r.xn_tm = t.xn_tm; r.slabin = d(t.slabin, 1); r.xn_pipe = d(t.xn_pipe, 0);
     return r;
 }
 
@@ -1171,7 +1171,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
         BneckParams bp;
         const int rc = fill_xn_params(h, o, n, &bp);
         if (rc) return rc;
-        e = launch_bneck(bp, 256, xn_tile(h, o, n), side ? h->side : h->stream);
+        e = launch_bneck(bp, 256, xn_tile(h, o, n) + (h->tune.xn_pipe ? 1000 : 0), side ? h->side : h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, "bneck_chain_f16 (no 3x3):" + o.name + ": " + hipGetErrorString(e));
         return YH_OK;
     }
@@ -1683,7 +1683,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->slabin = t.slabin; out->tfl_fuse = 1;
+    out->xn_tm = t.xn_tm; out->slabin = t.slabin; out->tfl_fuse = 1; out->xn_pipe = t.xn_pipe;
     return YH_OK;
 }
 
@@ -2548,7 +2548,7 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 // expand conv + next reduce conv: both convolutions' FLOPs; HBM bytes = b + residual in, y + a' out, the weights
                 const Op& oa = h->ops[o.xn_a];
                 const double px = (double)n * o.P * o.Q;
-                h->prof_labels[i] = std::string(bneck_symbol(256, xn_tile(h, o, n), true, false)) + ":" + o.name + "+" + oa.name;
+                h->prof_labels[i] = std::string(bneck_symbol(256, xn_tile(h, o, n) + (h->tune.xn_pipe ? 1000 : 0), true, false)) + ":" + o.name + "+" + oa.name;
                 fl += oa.flops_per_img * n;
                 by = 2.0 * px * (256.0 + 1024.0 + 1024.0) + px * 256.0 * ((oa.write_f16 || !h->fp8_active ? 2.0 : 0.0) + (h->fp8_active && oa.write_q ? 1.0 : 0.0)) + o.bytes_fixed + oa.bytes_fixed;
             } else if (o.kind == OP_CONV && chain_active(h, o, n)) {
