@@ -117,9 +117,10 @@ typedef struct yh_tuning {
     int32_t xn_tm;           /* layer 3's expand + next-reduce launch, pixel tile: -1 (default) 64-pixel tiles for about one round of
                               * workgroups (bneck_xn_f16), else separate launches; 64 / 128: that form wherever the launch is eligible
                               * (128: bneck_xn128_f16, bit-identical, measured no faster than the separate launches at batch 64) */
-    int32_t slabin;          /* reserved (-1) */
     int32_t xn_pipe;         /* layer 3's expand + next-reduce launch: 1 the pipelined kernel (bneck_xn2_f16: one barrier per chunk, GEMM 2 of
                               * chunk t beside GEMM 3 of chunk t - 1, W_a' fragments in registers), 0 the two-phase kernels; same bytes */
+    int32_t fp8_s3;          /* fp8 precision: launches of about one 128 x 128 tile per CU on a ring of three LDS stages (two tiles in flight)
+                              * instead of 64 x 64 tiles (YOLACT-700 R101 at 8 frames: layer 3); same bytes */
     int32_t tfl_fuse;        /* TFLite path: 1 (default) element-wise operators (QUANTIZE / RELU / RELU6 / TANH / ADD), PAD and contiguous
                               * CONCATENATION parts folded into the launch of the convolution / resize that produces their operand -
                               * same bytes, fewer launches; 0: one launch per operator, every tensor materialised (the checker) */

