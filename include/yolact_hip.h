@@ -124,6 +124,9 @@ typedef struct yh_tuning {
     int32_t tfl_fuse;        /* TFLite path: 1 (default) element-wise operators (QUANTIZE / RELU / RELU6 / TANH / ADD), PAD and contiguous
                               * CONCATENATION parts folded into the launch of the convolution / resize that produces their operand -
                               * same bytes, fewer launches; 0: one launch per operator, every tensor materialised (the checker) */
+    int32_t tfl_streams;     /* TFLite path: streams the plan's independent launches are spread over inside an invoke (forked from and joined
+                              * into the handle's stream; at most 8); 1 (default): everything on the handle's stream. Same bytes; measured neutral
+                              * on the 136-op model (its backbone is a chain), kept as a knob. A captured plan (tfl_graph = 1) keeps one lane */
 } yh_tuning;
 
 typedef struct yh_config {
