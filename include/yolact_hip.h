@@ -90,8 +90,9 @@ typedef struct yh_tuning {
                               * descriptors: the loads issue, nothing moves), bit 2 issues no loader instruction at all */
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
-    int32_t tfl_dot;         /* TFLite path, CONV_2D: 0 one lane per output element, 1 the v_dot4 kernel (Ci % 4 == 0), 2 (default) also the
-                              * int8 MFMA kernel where Ci % 64 == 0; all three give the same bytes */
+    int32_t tfl_dot;         /* TFLite path, CONV_2D: 0 one lane per output element, 1 the v_dot4 kernel (Ci % 4 == 0), 2 also the int8 MFMA
+                              * kernel on LDS tiles where Ci % 64 == 0, 3 (default) the int8 MFMA kernel fed from registers (one wave per
+                              * 32 x 32 tile, no LDS, eight k-steps of loads in flight) where Ci % 16 == 0; all four give the same bytes */
     int32_t tfl_graph;       /* TFLite path: 0 eager launches (default, and the faster form: 1.10 vs 1.22 ms), 1 hipGraph replay
                               * of the plan (captured with a second, one-node branch: DESIGN.md §8 on single-branch graphs) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0 keeps them on
@@ -127,6 +128,11 @@ typedef struct yh_tuning {
     int32_t tfl_streams;     /* TFLite path: streams the plan's independent launches are spread over inside an invoke (forked from and joined
                               * into the handle's stream; at most 8); 1 (default): everything on the handle's stream. Same bytes; measured neutral
                               * on the 136-op model (its backbone is a chain), kept as a knob. A captured plan (tfl_graph = 1) keeps one lane */
+    int32_t splitk_inl;      /* split-K convolutions: 1 the workgroup whose K slice arrives last sums the tile's slabs and runs the epilogue
+                              * inside the launch (one arrival counter per tile, nobody waits); 0 (default): splitk_reduce_f16 does, as a
+                              * second launch. Same bytes (the slabs are summed in slice order in both forms). Measured: 16 launches fewer
+                              * at batch 1 and the step SLOWER (0.718 -> 0.896 ms; batch 4: 1.269 -> 1.390) - one workgroup reads a tile's
+                              * 8-16 slabs alone where the reduce launch spreads them over the chip */
 } yh_tuning;
 
 typedef struct yh_config {

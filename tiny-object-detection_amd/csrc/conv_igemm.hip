@@ -629,6 +629,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                 }
         }
         __syncthreads();
+        f32x4 s0[SPLITK ? NPASS : 1], s1[SPLITK ? NPASS : 1];   // (split-K, in-launch reduction: the tile's summed rows)
         if (SPLITK) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -639,12 +640,49 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     *(f32x4*)(dst + 4) = *(const f32x4*)(E + m_l * ES + ch_l + 4);
                 }
             }
-        } else if (ch_ok) {
+            if (!p.tile_cnt) return;   // splitk_reduce_f16 finishes the convolution
+            // In-launch reduction (the counter form of the guide's split-K recipe): every wave's slab stores have completed, ONE lane
+            // releases them at agent scope and draws a ticket; the workgroup that draws the last one acquires, sums the tile's slabs
+            // in slice order (the order of splitk_reduce_f16: the bits are the same) and runs the epilogue. Nobody waits for
+            // anybody: a workgroup that is not last is done. The counter goes back to zero for the next launch that uses it
+            // (launches that share counters are ordered on one stream).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // (also: every read of E is over - its first word now carries the verdict)
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned ticket = __hip_atomic_fetch_add(p.tile_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = ticket == (unsigned)(p.k_slices - 1);
+                if (last) {
+                    __hip_atomic_store(p.tile_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *(volatile int*)lds = last;
+            }
+            __syncthreads();
+            if (!*(volatile int*)lds) return;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) { s0[pass] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; s1[pass] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; }
+            const long long slab = (long long)p.M * p.partial_ld;
+            for (int sl = 0; sl < p.k_slices; ++sl) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {   // (NPASS rows' loads in flight per slice)
+                    const int m = m_tile * TM + pass * RPP + rr;
+                    const float* src = p.partial + sl * slab + (long long)(m < p.M ? m : 0) * p.partial_ld + ch;
+                    s0[pass] += *(const f32x4*)src;
+                    s1[pass] += *(const f32x4*)(src + 4);
+                }
+            }
+        }
+        if (ch_ok) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
                 if (m < p.M) {
-                    const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
+                    f32x4 v0, v1;
+                    if (SPLITK) { v0 = s0[pass]; v1 = s1[pass]; }
+                    else { v0 = *(const f32x4*)(E + m_l * ES + ch_l); v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4); }
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -654,6 +692,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     long long yo, ro;
                     offsets(m, yo, ro);
                     if (p.res) {
+                        if (SPLITK) rv[pass] = load_residual<true>(p, m, ch, ro);   // (the reducer asks for its residual rows here; p.res_up is looked at at run time, as splitk_reduce_f16 does)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
                     }
@@ -858,23 +897,25 @@ hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t stream) {
 }
 
 // Sums the split-K partial slabs in slice order, then the usual epilogue. One lane = 8 channels of
-// one output row: 32-byte f32 reads per slice, one 16-byte f16 store.
+// one output row: 32-byte f32 reads per slice, one 16-byte f16 store. The slices' loads are issued eight (then four, two, one)
+// at a time and added in slice order: as a plain loop over the run-time slice count the compiler waited for every slice's
+// loads before it asked for the next one's, and the launch took k_slices L2 latencies (6.8 us on average at batch 1).
+template <int NB>
+__device__ __forceinline__ void splitk_add(const float*& src, long long slab, float v[8]) {
+    f32x4 a[NB], b[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { a[i] = *(const f32x4*)(src + i * slab); b[i] = *(const f32x4*)(src + i * slab + 4); }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[i][e]; v[4 + e] += b[i][e]; }
+    src += NB * slab;
+}
 __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
     const int groups = p.cout8 >> 3;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)p.M * groups) return;
     const int m = (int)(t / groups), ch = (int)(t - (long long)m * groups) * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-    for (int sl = 0; sl < p.k_slices; ++sl) {
-        const float* src = p.partial + ((long long)sl * p.M + m) * p.partial_ld + ch;
-        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] + p.bias[ch + e];
     long long yo, ro;
     if (p.y_dense) { yo = (long long)m * p.ldy + ch; ro = (long long)m * p.ldres + ch; }
     else {
@@ -882,8 +923,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
         yo = n * p.y_img_stride + (long long)rem * p.ldy + ch;
         ro = n * p.res_img_stride + (long long)rem * p.ldres + ch;
     }
+    // (the residual row and the bias are asked for in front of the slabs: one latency for all of them)
+    half8 rv;
+    if (p.res) rv = load_residual<true>(p, m, ch, ro);
+    const f32x4 b0 = *(const f32x4*)(p.bias + ch), b1 = *(const f32x4*)(p.bias + ch + 4);   // (bias is padded to coutPad)
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    {
+        const float* src = p.partial + (long long)m * p.partial_ld + ch;
+        const long long slab = (long long)p.M * p.partial_ld;
+        int left = p.k_slices;
+        for (; left >= 8; left -= 8) splitk_add<8>(src, slab, v);
+        if (left & 4) splitk_add<4>(src, slab, v);
+        if (left & 2) splitk_add<2>(src, slab, v);
+        if (left & 1) splitk_add<1>(src, slab, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = v[e] + b0[e]; v[4 + e] = v[4 + e] + b1[e]; }
     if (p.res) {
-        const half8 rv = load_residual<true>(p, m, ch, ro);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
     }

@@ -129,7 +129,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3, splitk_inl;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -142,7 +142,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
-    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0);
+    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0); r.splitk_inl = d(t.splitk_inl, 0);
     return r;
 }
 
@@ -232,6 +232,11 @@ struct yh_engine {
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     int head_fork_op = 0;   // ops[head_fork_op .. tail_fork_op) are the shared prediction head; the protonet does not read them
     float* splitk_ws_side = nullptr;   // split-K workspace of convolutions launched on the side stream
+    // In-launch split-K reduction (tune.splitk_inl): arrival counters per output tile, zero between launches - one array per stream
+    // that carries split-K convolutions (launches on one stream are ordered, so they share theirs).
+    static constexpr int kSplitKTiles = 4096;
+    unsigned* splitk_cnt = nullptr;
+    unsigned* splitk_cnt_side = nullptr;
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
 
@@ -873,8 +878,9 @@ int tail_split_tiles(const Tune& tu, int coutPad, const ConvParams& p, ConvTile 
 struct KLaunch { bool reduce; ConvParams p; ConvTile tile; double frac; const char* what; };
 
 int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
-    if (p.k_slices > 1) {   // split-K: main kernel + slab reduction
+    if (p.k_slices > 1) {   // split-K: main kernel + slab reduction (inside the main kernel where p.tile_cnt is set)
         out[0] = KLaunch{ false, p, tile, 1.0, "/splitk" };
+        if (p.tile_cnt) return 1;
         out[1] = KLaunch{ true, p, tile, 0.0, "" };
         return 2;
     }
@@ -1027,6 +1033,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = pn.coutPad;
             p.partial = h->splitk_ws;
+            if (h->tune.splitk_inl && tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
     }
     if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
@@ -1195,7 +1202,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
             ConvTile tile;
             int rc = fill_conv_params(h, o, n, &p, &tile);
             if (rc) return rc;
-            if (side && p.partial) p.partial = h->splitk_ws_side;
+            if (side && p.partial) { p.partial = h->splitk_ws_side; if (p.tile_cnt) p.tile_cnt = h->splitk_cnt_side; }
             e = launch_conv_planned(h->tune, p, tile, h->panels[o.panel].coutPad, side ? h->side : h->stream);
             break;
         }
@@ -1625,6 +1632,10 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
         h->splitk_ws = (float*)q;
         if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
         h->splitk_ws_side = (float*)q;
+        if ((rc = dev_alloc(h, &q, 2 * yh_engine::kSplitKTiles * sizeof(unsigned)))) return bail(rc);
+        if (hipMemset(q, 0, 2 * yh_engine::kSplitKTiles * sizeof(unsigned)) != hipSuccess) { h->err = "split-K counters: memset failed"; return bail(YH_EHIP); }
+        h->splitk_cnt = (unsigned*)q;
+        h->splitk_cnt_side = h->splitk_cnt + yh_engine::kSplitKTiles;
     }
     e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
@@ -1685,7 +1696,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3;
+    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl;
     return YH_OK;
 }
 
@@ -2659,6 +2670,7 @@ static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = coutPad;
             p.partial = h->splitk_ws;
+            if (h->tune.splitk_inl && (long long)((p.M + conv_tile_m(tile) - 1) / conv_tile_m(tile)) * p.n_ch_tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
         e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -2725,6 +2737,7 @@ int yh_op_conv2d_dual_f16(yh_engine* h, const uint16_t* x1, int32_t n, int32_t h
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = coutPad;
             p.partial = h->splitk_ws;
+            if (h->tune.splitk_inl && (long long)((p.M + conv_tile_m(tile) - 1) / conv_tile_m(tile)) * p.n_ch_tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
         e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -197,17 +197,18 @@ struct ConvI8 {
 typedef int v4i __attribute__((ext_vector_type(4)));
 // Epilogue of the int8 MFMA convolutions: lane = pixel (wm, j, l15), channels (wc, i, 4 lg + e) [C/D layout of the 16 x 16 MFMA:
 // column = lane & 15, rows 4 (lane >> 4) + e]; sx[j] = sum of the raw input bytes over the whole K of pixel (wm, j, l15).
-__device__ __forceinline__ void conv_i8_epilogue(const ConvI8& p, const v4i (&acc)[2][2], const unsigned (&sx)[2], int m0, int ch0, int wc, int wm, int l15, int lg, int HoWo) {
+template <int TI, int TJ>   // MFMA tiles per wave along the channels / the pixels
+__device__ __forceinline__ void conv_i8_epilogue(const ConvI8& p, const v4i (&acc)[TI][TJ], const unsigned (&sx)[TJ], int m0, int ch0, int wc, int wm, int l15, int lg, int HoWo) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int mo = m0 + wm * 32 + j * 16 + l15;
+    for (int j = 0; j < TJ; ++j) {
+        const int mo = m0 + wm * 16 * TJ + j * 16 + l15;
         if (mo >= p.M) continue;
         const int im = mo / HoWo, px = mo - im * HoWo;
         uint8_t* yrow = p.y + (long long)im * p.ys + (size_t)px * p.Co;
         const int xterm = (128 - p.zw) * ((int)sx[j] - 128 * p.K);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = ch0 + wc * 32 + i * 16 + 4 * lg;
+        for (int i = 0; i < TI; ++i) {
+            const int ch = ch0 + wc * 16 * TI + i * 16 + 4 * lg;
             if (ch >= p.Co) continue;
             unsigned packed = 0;
 #pragma unroll
@@ -314,7 +315,108 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
         sx[j] += __shfl_xor(sx[j], 16);
         sx[j] += __shfl_xor(sx[j], 32);
     }
-    conv_i8_epilogue(p, acc, sx, m0, ch0, wc, wm, l15, lg, HoWo);
+    conv_i8_epilogue<2, 2>(p, acc, sx, m0, ch0, wc, wm, l15, lg, HoWo);
+}
+
+// ---- The same convolution with NO LDS and no barrier (yh_tuning.tfl_dot = 3, the default, for the launches conv_i8_direct_pays()
+// names): one wave = ONE 16 x 16 MFMA tile, and every operand register is one 16-byte global load - lane (l15, lg) of
+// v_mfma_i32_16x16x64_i8 holds bytes 16 lg .. 16 lg + 15 of row l15's 64-deep K chunk, which is contiguous both in the weight panel
+// [Co][K] and in an NHWC pixel's channels. What a launch of the LDS tiles costs (tools/study/tfl_layer_table.py: the per-launch
+// timeline of the 136-op model) is not its MFMAs: it is the serial k-loop (0.36 us per step: stash / barrier / fragment reads on
+// waves that have their SIMD to themselves) and the epilogue - 16 outputs per lane, each a fixed-point requantisation and, where an
+// ADD or a LUT is folded in, that arithmetic too (a projection convolution with the residual ADD folded in: 15.6 us against 8.5
+// without) - on 2 to 50 workgroups of a 256-CU chip. Here a lane finishes 4 outputs, a 7-workgroup layer becomes 100 waves, a k-step
+// is 2 loads, 4 v_dot4, 4 v_xor and 1 MFMA, and D steps of loads are in flight (a ring of registers indexed at compile time). The
+// re-reads of the operands (each weight row by every pixel tile, each pixel by every channel tile) are L2 hits. K chunks past Ci
+// (Ci % 16 == 0, not % 64: 16, 32, 96, 144 channels) are fed zeros on both sides, which add nothing to sum x'w' nor to sum x.
+// D = the depth of the register ring = the k-steps of one loop iteration. The loop body has NO branch: with a wave-uniform
+// `if (step < nsteps)` around each step hipcc's wait insertion gave up counting and put s_waitcnt vmcnt(0..3) in front of every step
+// - eight steps of loads "in flight" that were waited for one by one. So the k-steps are rounded up to a multiple of D (the launch
+// picks the D that pads least), and the steps past the end load the last step again and are fed zeros.
+template <int D>
+__global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
+    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.x * 16, ch0 = blockIdx.y * 16;
+    const int HoWo = p.Ho * p.Wo;
+    const int m = m0 + l15;
+    const bool live = m < p.M;
+    const int img = live ? m / HoWo : 0, rem = live ? m - img * HoWo : 0, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const uint8_t* const xb = p.x + (long long)img * p.xs + lg * 16;
+    const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
+    const uint8_t* const wa = p.wq + (size_t)(ch0 + l15) * p.K + lg * 16;   // (rows up to CoPad exist)
+    const int cchunks = (p.Ci + 63) >> 6, nsteps = p.kh * p.kw * cchunks;
+    const int zx4 = (int)((unsigned)p.zx * 0x01010101u);
+    struct Tile { v4i a, b; };
+    int f_r = 0, f_s = 0, f_cc = 0, f_tap = 0, f_n = 0;   // the next k-step to fetch: tap (f_r, f_s) = f_tap, 64-channel chunk f_cc
+    auto fetch = [&]() {
+        Tile t;
+        const bool more = f_n < nsteps;   // (wave-uniform; past the end the position stays on the last step and the tile is zeros)
+        const bool cin = f_cc * 64 + lg * 16 < p.Ci;   // (per lane group: the last chunk of a Ci that is not a multiple of 64)
+        const bool use = more && cin;
+        const int coff = cin ? f_cc * 64 : 0;
+        const v4i va = *(const v4i*)(wa + f_tap * p.Ci + coff);
+        const int iy = iy0 + f_r * p.dh, ix = ix0 + f_s * p.dw;
+        const bool in = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        // padded tap (and rows past M): x = zx contributes (x - zx) = 0. (The address is clamped into the image, the value selected.)
+        const v4i vb = *(const v4i*)(xb + (unsigned)(((in ? iy : 0) * p.W + (in ? ix : 0)) * p.Ci + coff));
+        t.a = use ? va : v4i{ 0, 0, 0, 0 };
+        t.b = !use ? v4i{ 0, 0, 0, 0 } : (in ? vb : v4i{ zx4, zx4, zx4, zx4 });
+        // advance (selects, no branch); the last step is never left
+        const int adv = f_n + 1 < nsteps;
+        f_n += more;
+        const int ncc = f_cc + 1, wrap_c = ncc == cchunks;
+        const int ns = f_s + 1, wrap_s = wrap_c && ns == p.kw;
+        f_cc = adv ? (wrap_c ? 0 : ncc) : f_cc;
+        f_tap = adv ? f_tap + wrap_c : f_tap;
+        f_s = adv ? (wrap_c ? (wrap_s ? 0 : ns) : f_s) : f_s;
+        f_r = adv ? f_r + wrap_s : f_r;
+        return t;
+    };
+    v4i acc[1][1] = { { v4i{ 0, 0, 0, 0 } } };
+    unsigned sx[1] = { 0u };
+    Tile ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = fetch();
+    for (int step = 0; step < nsteps; step += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const Tile t = ring[d];
+            ring[d] = fetch();   // (k-step step + d + D: asked for before this step's MFMA is issued)
+            v4i fb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sx[0] = __builtin_amdgcn_udot4((unsigned)t.b[e], 0x01010101u, sx[0], false);
+                fb[e] = t.b[e] ^ (int)0x80808080u;
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t.a, fb, acc[0][0], 0, 0, 0);
+        }
+    }
+    sx[0] += __shfl_xor(sx[0], 16);
+    sx[0] += __shfl_xor(sx[0], 32);
+    conv_i8_epilogue<1, 1>(p, acc, sx, m0, ch0, 0, 0, l15, lg, HoWo);
+}
+// The ring depth for a launch of n k-steps: the D of {1 2 3 4 5 6 8 9} that pads n least, the deepest among equals.
+static int conv_i8_direct_depth(int n) {
+    static const int ds[] = { 9, 8, 6, 5, 4, 3, 2, 1 };
+    int best = 1, pad = 1 << 30;
+    for (int d : ds) { if (d > n) continue; const int q = (n + d - 1) / d * d - n; if (q < pad) { pad = q; best = d; } }
+    return best;
+}
+template <int D>
+static void launch_conv_i8_direct_d(const ConvI8& q, hipStream_t s) {
+    hipLaunchKernelGGL(tfl_conv_i8_direct<D>, dim3((unsigned)((q.M + 15) / 16), (unsigned)((q.Co + 15) / 16)), dim3(64), 0, s, q);
+}
+static void launch_conv_i8_direct(const ConvI8& q, hipStream_t s) {
+    switch (conv_i8_direct_depth(q.kh * q.kw * ((q.Ci + 63) / 64))) {
+        case 1: launch_conv_i8_direct_d<1>(q, s); break;
+        case 2: launch_conv_i8_direct_d<2>(q, s); break;
+        case 3: launch_conv_i8_direct_d<3>(q, s); break;
+        case 4: launch_conv_i8_direct_d<4>(q, s); break;
+        case 5: launch_conv_i8_direct_d<5>(q, s); break;
+        case 6: launch_conv_i8_direct_d<6>(q, s); break;
+        case 8: launch_conv_i8_direct_d<8>(q, s); break;
+        default: launch_conv_i8_direct_d<9>(q, s); break;
+    }
 }
 
 // (Round 4 also built the same convolution with its K split over the four waves of the workgroup - every wave the whole 64 x 64
@@ -498,7 +600,7 @@ struct yh_tfl {
     std::vector<hipEvent_t> ev_end;   // per side lane
     int use_fuse = 1;                 // yh_tuning.tfl_fuse: element-wise operators / PAD / CONCATENATION parts folded into their producers (fuse_plan)
     std::vector<char> gone;           // tensor i is never written by the fused plan (yh_tfl_tensor_read says so)
-    int use_dot = 2, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel where Ci % 64 == 0: default) / tfl_graph
+    int use_dot = 3, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel on LDS tiles where Ci % 64 == 0, 3 + its register-fed form where Ci % 16 == 0: default) / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* side_word = nullptr;
@@ -566,7 +668,7 @@ int prepare(yh_tfl* h) {
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
                 c.wsum = nullptr;
-                if (!dw && h->use_dot >= 2 && c.Ci % 64 == 0 && w.data && (long long)c.kh * c.kw * c.Ci < 131072) {
+                if (!dw && h->use_dot >= 2 && c.Ci % (h->use_dot >= 3 ? 16 : 64) == 0 && w.data && (long long)c.kh * c.kw * c.Ci < 131072) {
                     // int8 MFMA form: the weight panel as int8 (w ^ 0x80) padded to 64-channel tiles, and per channel
                     //   cterm = (128 - zx) sum(w - 128) + K (128 - zx)(128 - zw) + bias   (all exact in int32: |.| < 2^31 for K < 2^17)
                     const int K = c.kh * c.kw * c.Ci, CoPad = (c.Co + 63) / 64 * 64;
@@ -943,7 +1045,8 @@ int enqueue_plan(yh_tfl* h) {
             case P_CONV_I8: {
                 ConvI8 q = p.ci8;
                 q.M = q.Ho * q.Wo * (int)nb;
-                hipLaunchKernelGGL(tfl_conv_i8_mfma, dim3((unsigned)((q.M + 63) / 64), (unsigned)((q.Co + 63) / 64)), dim3(256), 0, s, q);
+                if (h->use_dot >= 3) launch_conv_i8_direct(q, s);
+                else hipLaunchKernelGGL(tfl_conv_i8_mfma, dim3((unsigned)((q.M + 63) / 64), (unsigned)((q.Co + 63) / 64)), dim3(256), 0, s, q);
                 break;
             }
             case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv); break;

@@ -93,6 +93,8 @@ struct ConvParams {
     int ksteps_per_slice;
     int partial_ld;       // row stride of the partial slabs in floats (coutPad)
     float* partial;       // [k_slices][M][partial_ld] f32 workspace
+    unsigned* tile_cnt;   // split-K: one arrival counter per output tile (zero between launches). Set: the workgroup whose slice arrives
+                          // last sums the tile's slabs and runs the epilogue inside the launch; nullptr: splitk_reduce_f16 does, as a launch
 };
 
 // (ids 4 and 9-11 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel - DESIGN.md §4)
