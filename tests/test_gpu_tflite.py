@@ -336,12 +336,12 @@ def test_batch_plan_two_tiles_in_one_invoke_equals_two_invokes(built, graph):
 
 
 def test_int8_mfma_conv_geometries_bit_exact(built):
-    """CONV_2D with Ci % 16 == 0 runs on v_mfma_i32_16x16x64_i8 (yh_tuning.tfl_dot = 3, the default: one wave per 32 x 32 tile,
-    operands loaded straight into the MFMA's registers, K chunks past Ci fed zeros; tfl_dot = 2: 64 x 64 tiles through LDS, Ci %
+    """CONV_2D with Ci % 4 == 0 runs on v_mfma_i32_16x16x64_i8 (yh_tuning.tfl_dot = 3, the default: one wave per 16 x 16 tile,
+    operands loaded straight into the MFMA's registers, dwords past Ci fed zeros; tfl_dot = 2: 64 x 64 tiles through LDS, Ci %
     64 == 0 - other layers on the v_dot4 kernel): uint8 operands flipped to int8, sum(x'w') in int32, TFLite's value restored exactly from sum x' (v_dot4 beside the MFMAs), sum w' (tabulated) and the
     zero points; a padded tap is fed the zero point. Seeded sweep: kernel 1/3/5, stride 1/2, SAME/VALID, every fused activation,
     output channels around the 64-channel tile and not a multiple of 4 (243: byte stores), pixel counts around the 64-pixel
-    tile, one and two images per invoke, input channels 16 ... 192 (the tail chunk of 16, 32, 48, 96 and 144 channels) - against
+    tile, one and two images per invoke, input channels 4 ... 192 (the tail chunk of 4, 8, 16, 24, 32, 48, 96 and 144 channels) - against
     the numpy oracle under every tfl_dot, bit for bit."""
     import tfl_oracle as O
     import yolact_amd as ya
@@ -350,7 +350,7 @@ def test_int8_mfma_conv_geometries_bit_exact(built):
         k, stride = int(rng.choice([1, 3, 3, 5])), int(rng.choice([1, 1, 2]))
         h, w = int(rng.integers(k, 24)), int(rng.integers(k, 24))
         kw = dict(k=k, stride=stride, padding=int(rng.integers(0, 2)), act=int(rng.choice([0, 1, 3])), h=h, w=w,
-                  ci=int(rng.choice([64, 128, 192] if it < 24 else [16, 32, 48, 96, 144, 160])), co=int(rng.choice([1, 12, 31, 33, 63, 64, 65, 96, 128, 243])), so=float(rng.uniform(0.05, 0.6)))
+                  ci=int(rng.choice([64, 128, 192] if it < 24 else [4, 8, 16, 24, 32, 48, 96, 144, 160])), co=int(rng.choice([1, 12, 31, 33, 63, 64, 65, 96, 128, 243])), so=float(rng.uniform(0.05, 0.6)))
         model = M.single_op("CONV_2D", rng, **kw)
         t_in = model.tensors[model.inputs[0]]
         blob = B.serialize(model)

@@ -76,6 +76,8 @@ __device__ __forceinline__ int apply_post(const PostOps& po, int q, long long im
     return q;
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));   // (a 16-byte load from a dword-aligned address)
 struct ConvQ {
     const uint8_t *x, *w; const int* bias; uint8_t* y;
     int H, W, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, dm;
@@ -106,6 +108,73 @@ __global__ __launch_bounds__(256) void tfl_conv_u8(const ConvQ p) {
     }
     acc += p.bias ? p.bias[oc] : 0;
     py[t] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.y, t);
+}
+
+// The same for layers the dot-product and MFMA kernels cannot take (Ci % 4 != 0: the model's first convolution, 3 channels) when
+// yh_tuning.tfl_dot >= 1: one lane = one pixel x 8 output channels instead of one output element. The workgroup (256 pixels x 8
+// channels) first puts its 8 x K weights, zero point already subtracted, into LDS as [k][8] ints: a lane then loads each input byte
+// once for eight MACs and reads its weights with two broadcast ds_read_b128 (the element-per-lane kernel loads an input byte and a
+// weight byte per MAC: 19.2 us for the 224 x 224 x 3 -> 112 x 112 x 32 layer of two images; this form: see DESIGN.md section 8).
+constexpr int kPx8MaxK = 512;   // taps x input channels a launch of this kernel can hold (16 KB of LDS)
+template <int KH, int KW, int CI>   // (0, 0, 0: run-time extent; 3, 3, 3: the RGB stem)
+__global__ __launch_bounds__(256) void tfl_conv_u8_px8(const ConvQ p) {
+    __shared__ __attribute__((aligned(16))) int wl[kPx8MaxK * 8];
+    const int K = p.kh * p.kw * p.Ci, oc0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < K * 8; i += 256) {
+        const int k = i >> 3, j = i & 7, oc = oc0 + j < p.Co ? oc0 + j : p.Co - 1;   // (the clamped duplicates are not stored)
+        wl[i] = (int)p.w[(size_t)oc * K + k] - p.zw;
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= p.Ho * p.Wo) return;
+    const uint8_t* const px = p.x + blockIdx.z * p.xs;
+    uint8_t* const py = p.y + blockIdx.z * p.ys;
+    const int ox = pix % p.Wo, oy = pix / p.Wo;
+    int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if constexpr (KH > 0) {   // extent known at compile time: every input byte of the lane is asked for before the first MAC
+        int xv[KH * KW * CI];
+#pragma unroll
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                const int iy = oy * p.sh - p.ph + r * p.dh, ix = ox * p.sw - p.pw + s * p.dw;
+                const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint8_t* xp = px + ((size_t)(in ? iy : 0) * p.W + (in ? ix : 0)) * CI;
+#pragma unroll
+                for (int c = 0; c < CI; ++c) { const int v = (int)xp[c]; xv[(r * KW + s) * CI + c] = in ? v - p.zx : 0; }
+            }
+#pragma unroll
+        for (int k = 0; k < KH * KW * CI; ++k) {
+            const v4i w0 = *(const v4i*)(wl + k * 8), w1 = *(const v4i*)(wl + k * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += xv[k] * w0[j]; acc[4 + j] += xv[k] * w1[j]; }
+        }
+    } else {
+        for (int r = 0; r < p.kh; ++r) {
+            const int iy = oy * p.sh - p.ph + r * p.dh;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int s = 0; s < p.kw; ++s) {
+                const int ix = ox * p.sw - p.pw + s * p.dw;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const uint8_t* xp = px + ((size_t)iy * p.W + ix) * p.Ci;
+                const int* wk = wl + (r * p.kw + s) * p.Ci * 8;
+                for (int c = 0; c < p.Ci; ++c) {
+                    const int xv = (int)xp[c] - p.zx;
+                    const v4i w0 = *(const v4i*)(wk + c * 8), w1 = *(const v4i*)(wk + c * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[j] += xv * w0[j]; acc[4 + j] += xv * w1[j]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int oc = oc0 + j;
+        if (oc < p.Co) {
+            const int a = acc[j] + (p.bias ? p.bias[oc] : 0);
+            py[(size_t)pix * p.Co + oc] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.z, (long long)pix * p.Co + oc);
+        }
+    }
 }
 
 // Same arithmetic, four MACs per instruction: for Ci % 4 == 0 the sum over the valid taps of
@@ -194,7 +263,6 @@ struct ConvI8 {
     long long xs, ys;
     PostOps po;
 };
-typedef int v4i __attribute__((ext_vector_type(4)));
 // Epilogue of the int8 MFMA convolutions: lane = pixel (wm, j, l15), channels (wc, i, 4 lg + e) [C/D layout of the 16 x 16 MFMA:
 // column = lane & 15, rows 4 (lane >> 4) + e]; sx[j] = sum of the raw input bytes over the whole K of pixel (wm, j, l15).
 template <int TI, int TJ>   // MFMA tiles per wave along the channels / the pixels
@@ -333,55 +401,74 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
 // `if (step < nsteps)` around each step hipcc's wait insertion gave up counting and put s_waitcnt vmcnt(0..3) in front of every step
 // - eight steps of loads "in flight" that were waited for one by one. So the k-steps are rounded up to a multiple of D (the launch
 // picks the D that pads least), and the steps past the end load the last step again and are fed zeros.
-template <int D>
+// ONCE: the launch has exactly D k-steps - every load of the wave is asked for before its first MFMA and nothing is fetched again
+// (the 3x3 x 128-channel head convolutions, 18 steps: 9.5 -> 7 us against two drained iterations of a ring of 9).
+// KK (ONCE only): the kernel extent, 1 x 1 or 3 x 3 - the tap and the channel chunk of step d are then compile-time constants and
+// the position bookkeeping below disappears from the prologue (0: run-time extent, looped form).
+template <int D, bool ONCE, int KK>
 __global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
+    static_assert(KK == 0 || (ONCE && D % (KK * KK) == 0), "compile-time extents: the launch's k-steps are exactly D");
     const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.x * 16, ch0 = blockIdx.y * 16;
     const int HoWo = p.Ho * p.Wo;
     const int m = m0 + l15;
     const bool live = m < p.M;
     const int img = live ? m / HoWo : 0, rem = live ? m - img * HoWo : 0, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    const uint8_t* const xb = p.x + (long long)img * p.xs + lg * 16;
+    const uint8_t* const xb = p.x + (long long)img * p.xs;
     const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
-    const uint8_t* const wa = p.wq + (size_t)(ch0 + l15) * p.K + lg * 16;   // (rows up to CoPad exist)
+    const uint8_t* const wa = p.wq + (size_t)(ch0 + l15) * p.K;   // (rows up to CoPad exist)
     const int cchunks = (p.Ci + 63) >> 6, nsteps = p.kh * p.kw * cchunks;
     const int zx4 = (int)((unsigned)p.zx * 0x01010101u);
     struct Tile { v4i a, b; };
     int f_r = 0, f_s = 0, f_cc = 0, f_tap = 0, f_n = 0;   // the next k-step to fetch: tap (f_r, f_s) = f_tap, 64-channel chunk f_cc
-    auto fetch = [&]() {
+    auto fetch_at = [&](int r, int s_, int tap, int cc, bool more) {
         Tile t;
-        const bool more = f_n < nsteps;   // (wave-uniform; past the end the position stays on the last step and the tile is zeros)
-        const bool cin = f_cc * 64 + lg * 16 < p.Ci;   // (per lane group: the last chunk of a Ci that is not a multiple of 64)
-        const bool use = more && cin;
-        const int coff = cin ? f_cc * 64 : 0;
-        const v4i va = *(const v4i*)(wa + f_tap * p.Ci + coff);
-        const int iy = iy0 + f_r * p.dh, ix = ix0 + f_s * p.dw;
+        // (per lane group: the last chunk of a Ci that is not a multiple of 64 holds nd < 4 dwords of this lane's 16 bytes - the rest
+        // belongs to the next tap / pixel and is fed zeros; Ci % 4 == 0, so the loads are dword-aligned, not 16-byte aligned)
+        const int left = p.Ci - (cc * 64 + lg * 16), nd = !more ? 0 : (left >= 16 ? 4 : (left > 0 ? left >> 2 : 0));
+        const int coff = left > 0 ? cc * 64 + lg * 16 : 0;   // (a lane group past Ci reads its row's first bytes: nothing is read more than 12 bytes past a row)
+        const v4i va = *(const v4i_u*)(wa + tap * p.Ci + coff);
+        const int iy = iy0 + r * p.dh, ix = ix0 + s_ * p.dw;
         const bool in = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         // padded tap (and rows past M): x = zx contributes (x - zx) = 0. (The address is clamped into the image, the value selected.)
-        const v4i vb = *(const v4i*)(xb + (unsigned)(((in ? iy : 0) * p.W + (in ? ix : 0)) * p.Ci + coff));
-        t.a = use ? va : v4i{ 0, 0, 0, 0 };
-        t.b = !use ? v4i{ 0, 0, 0, 0 } : (in ? vb : v4i{ zx4, zx4, zx4, zx4 });
-        // advance (selects, no branch); the last step is never left
-        const int adv = f_n + 1 < nsteps;
-        f_n += more;
-        const int ncc = f_cc + 1, wrap_c = ncc == cchunks;
-        const int ns = f_s + 1, wrap_s = wrap_c && ns == p.kw;
-        f_cc = adv ? (wrap_c ? 0 : ncc) : f_cc;
-        f_tap = adv ? f_tap + wrap_c : f_tap;
-        f_s = adv ? (wrap_c ? (wrap_s ? 0 : ns) : f_s) : f_s;
-        f_r = adv ? f_r + wrap_s : f_r;
+        const v4i vb = *(const v4i_u*)(xb + (unsigned)(((in ? iy : 0) * p.W + (in ? ix : 0)) * p.Ci + coff));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t.a[e] = e < nd ? va[e] : 0;
+            t.b[e] = e < nd ? (in ? vb[e] : zx4) : 0;
+        }
         return t;
+    };
+    auto fetch = [&](int d) {
+        if constexpr (KK > 0) {
+            constexpr int CC = D / (KK * KK);
+            const int tap = d / CC;
+            return fetch_at(tap / KK, tap % KK, tap, d % CC, true);
+        } else {
+            // (wave-uniform position; past the end it stays on the last step and the tile is zeros)
+            const Tile t = fetch_at(f_r, f_s, f_tap, f_cc, f_n < nsteps);
+            // advance (selects, no branch); the last step is never left
+            const int adv = f_n + 1 < nsteps;
+            f_n += f_n < nsteps;
+            const int ncc = f_cc + 1, wrap_c = ncc == cchunks;
+            const int ns = f_s + 1, wrap_s = wrap_c && ns == p.kw;
+            f_cc = adv ? (wrap_c ? 0 : ncc) : f_cc;
+            f_tap = adv ? f_tap + wrap_c : f_tap;
+            f_s = adv ? (wrap_c ? (wrap_s ? 0 : ns) : f_s) : f_s;
+            f_r = adv ? f_r + wrap_s : f_r;
+            return t;
+        }
     };
     v4i acc[1][1] = { { v4i{ 0, 0, 0, 0 } } };
     unsigned sx[1] = { 0u };
     Tile ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = fetch();
-    for (int step = 0; step < nsteps; step += D) {
+    for (int d = 0; d < D; ++d) ring[d] = fetch(d);
+    for (int step = 0; step < (ONCE ? 1 : nsteps); step += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const Tile t = ring[d];
-            ring[d] = fetch();   // (k-step step + d + D: asked for before this step's MFMA is issued)
+            if (!ONCE) ring[d] = fetch(d);   // (k-step step + d + D: asked for before this step's MFMA is issued)
             v4i fb;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -395,28 +482,64 @@ __global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
     sx[0] += __shfl_xor(sx[0], 32);
     conv_i8_epilogue<1, 1>(p, acc, sx, m0, ch0, 0, 0, l15, lg, HoWo);
 }
-// The ring depth for a launch of n k-steps: the D of {1 2 3 4 5 6 8 9} that pads n least, the deepest among equals.
-static int conv_i8_direct_depth(int n) {
-    static const int ds[] = { 9, 8, 6, 5, 4, 3, 2, 1 };
-    int best = 1, pad = 1 << 30;
+// The ring depth for a launch of n k-steps: n itself where a kernel of that depth exists (ONCE), else the D of {9 8 6 5 4} that
+// pads n least, the deepest among equals.
+static int conv_i8_direct_depth(int n, bool* once) {
+    static const int exact[] = { 1, 2, 3, 4, 5, 6, 8, 9, 12, 15, 18 };
+    for (int d : exact) if (d == n) { *once = true; return d; }
+    *once = false;
+    static const int ds[] = { 9, 8, 6, 5, 4 };
+    int best = 4, pad = 1 << 30;
     for (int d : ds) { if (d > n) continue; const int q = (n + d - 1) / d * d - n; if (q < pad) { pad = q; best = d; } }
     return best;
 }
-template <int D>
+template <int D, bool ONCE, int KK>
 static void launch_conv_i8_direct_d(const ConvI8& q, hipStream_t s) {
-    hipLaunchKernelGGL(tfl_conv_i8_direct<D>, dim3((unsigned)((q.M + 15) / 16), (unsigned)((q.Co + 15) / 16)), dim3(64), 0, s, q);
+    hipLaunchKernelGGL((tfl_conv_i8_direct<D, ONCE, KK>), dim3((unsigned)((q.M + 15) / 16), (unsigned)((q.Co + 15) / 16)), dim3(64), 0, s, q);
 }
 static void launch_conv_i8_direct(const ConvI8& q, hipStream_t s) {
-    switch (conv_i8_direct_depth(q.kh * q.kw * ((q.Ci + 63) / 64))) {
-        case 1: launch_conv_i8_direct_d<1>(q, s); break;
-        case 2: launch_conv_i8_direct_d<2>(q, s); break;
-        case 3: launch_conv_i8_direct_d<3>(q, s); break;
-        case 4: launch_conv_i8_direct_d<4>(q, s); break;
-        case 5: launch_conv_i8_direct_d<5>(q, s); break;
-        case 6: launch_conv_i8_direct_d<6>(q, s); break;
-        case 8: launch_conv_i8_direct_d<8>(q, s); break;
-        default: launch_conv_i8_direct_d<9>(q, s); break;
+    bool once = false;
+    const int n = q.kh * q.kw * ((q.Ci + 63) / 64);
+    int d = conv_i8_direct_depth(n, &once);
+    const int kk = q.kh == 1 && q.kw == 1 ? 1 : (q.kh == 3 && q.kw == 3 ? 3 : 0);
+    if (once && kk == 3 && (d == 9 || d == 18)) {
+        if (d == 9) launch_conv_i8_direct_d<9, true, 3>(q, s); else launch_conv_i8_direct_d<18, true, 3>(q, s);
+        return;
     }
+    if (once && kk == 1) {
+        switch (d) {
+            case 1: launch_conv_i8_direct_d<1, true, 1>(q, s); break;
+            case 2: launch_conv_i8_direct_d<2, true, 1>(q, s); break;
+            case 3: launch_conv_i8_direct_d<3, true, 1>(q, s); break;
+            case 4: launch_conv_i8_direct_d<4, true, 1>(q, s); break;
+            case 5: launch_conv_i8_direct_d<5, true, 1>(q, s); break;
+            case 6: launch_conv_i8_direct_d<6, true, 1>(q, s); break;
+            case 8: launch_conv_i8_direct_d<8, true, 1>(q, s); break;
+            case 9: launch_conv_i8_direct_d<9, true, 1>(q, s); break;
+            case 12: launch_conv_i8_direct_d<12, true, 1>(q, s); break;
+            case 15: launch_conv_i8_direct_d<15, true, 1>(q, s); break;
+            default: launch_conv_i8_direct_d<18, true, 1>(q, s); break;
+        }
+        return;
+    }
+    // any other extent (or step count): the looped form
+    if (once) { d = n >= 9 ? 9 : (n >= 8 ? 8 : (n >= 6 ? 6 : (n >= 5 ? 5 : 4))); }
+    switch (d) {
+        case 4: launch_conv_i8_direct_d<4, false, 0>(q, s); break;
+        case 5: launch_conv_i8_direct_d<5, false, 0>(q, s); break;
+        case 6: launch_conv_i8_direct_d<6, false, 0>(q, s); break;
+        case 8: launch_conv_i8_direct_d<8, false, 0>(q, s); break;
+        default: launch_conv_i8_direct_d<9, false, 0>(q, s); break;
+    }
+}
+// Which int8 MFMA launches take the register-fed kernel: every one whose input channels the LDS tiles cannot take (Ci % 64 != 0), and
+// the small ones - up to 2048 waves (8 per CU), or up to 8 k-steps. A large layer with a long K (the protonet's 3x3 x 128 channels
+// at 56 x 56 x 2 images: 3136 waves of 18 steps) re-reads its operands once per 16 x 16 tile and measured 26.0 us against 14.2 on
+// the 64 x 64 LDS tiles.
+static bool conv_i8_direct_pays(const ConvI8& q) {
+    if (q.Ci % 64 != 0) return true;
+    const long long waves = (long long)((q.M + 15) / 16) * ((q.Co + 15) / 16);
+    return waves <= 2048 || q.kh * q.kw * (q.Ci / 64) <= 8;
 }
 
 // (Round 4 also built the same convolution with its K split over the four waves of the workgroup - every wave the whole 64 x 64
@@ -443,6 +566,50 @@ __global__ __launch_bounds__(256) void tfl_dwconv_u8(const ConvQ p) {
     }
     acc += p.bias ? p.bias[oc] : 0;
     py[t] = (uint8_t)apply_post(p.po, q_clamp(q_mbqm(acc, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.y, t);
+}
+
+// Depth multiplier 1, channels a multiple of 4, dword-aligned tensors, kernel extent known at compile time (3 x 3: every depthwise
+// layer of the model family): one lane = one pixel x FOUR channels - a tap is one dword of input and one dword of weights for four
+// MACs - and the loop over the taps has no branch: all KH x KW input dwords are asked for at once (a tap outside the image loads
+// from a clamped address and is given the zero point, (x - zx) = 0), so a lane waits one memory latency instead of one per tap. The
+// element-per-lane kernel above takes 5.2 us (small layers) to 10.7 us (112 x 112 x 32 x 2 images) per launch.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void tfl_dwconv_u8_c4(const ConvQ p) {
+    const int c4n = p.Co >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.Ho * p.Wo * c4n) return;
+    const uint8_t* const px = p.x + blockIdx.y * p.xs + 4 * (t % c4n);
+    uint8_t* const py = p.y + blockIdx.y * p.ys;
+    const int cg = t % c4n, r0 = t / c4n, ox = r0 % p.Wo, oy = r0 / p.Wo;
+    const unsigned zx4 = (unsigned)p.zx * 0x01010101u;
+    unsigned xv[KH * KW], wv[KH * KW];
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+            const int iy = oy * p.sh - p.ph + r * p.dh, ix = ox * p.sw - p.pw + s * p.dw;
+            const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned v = *(const unsigned*)(px + ((size_t)(in ? iy : 0) * p.W + (in ? ix : 0)) * p.Ci);
+            xv[r * KW + s] = in ? v : zx4;
+            wv[r * KW + s] = *(const unsigned*)(p.w + (size_t)(r * KW + s) * p.Co + 4 * cg);
+        }
+    int acc[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < KH * KW; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += ((int)((xv[k] >> (8 * e)) & 255u) - p.zx) * ((int)((wv[k] >> (8 * e)) & 255u) - p.zw);
+    const long long e0 = (long long)r0 * p.Co + 4 * cg;
+    unsigned packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int a = acc[e] + (p.bias ? p.bias[4 * cg + e] : 0);
+        packed |= (unsigned)apply_post(p.po, q_clamp(q_mbqm(a, p.mult, p.shift) + p.zo, p.lo, p.hi), blockIdx.y, e0 + e) << (8 * e);
+    }
+    if ((((size_t)py) & 3) == 0) *(unsigned*)(py + e0) = packed;   // (a CONCATENATION part may start at any byte)
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) py[e0 + e] = (uint8_t)(packed >> (8 * e));
+    }
 }
 
 // RESHAPE: a plain device copy as a kernel (a memcpy NODE in the captured plan crashed rocprofv3's
@@ -668,11 +835,11 @@ int prepare(yh_tfl* h) {
                 act_range(op.act, y.scale, y.zp, &c.lo, &c.hi);
                 pr.kind = dw ? P_DW : P_CONV;
                 c.wsum = nullptr;
-                if (!dw && h->use_dot >= 2 && c.Ci % (h->use_dot >= 3 ? 16 : 64) == 0 && w.data && (long long)c.kh * c.kw * c.Ci < 131072) {
+                if (!dw && h->use_dot >= 2 && c.Ci % (h->use_dot >= 3 ? 4 : 64) == 0 && (((size_t)c.x) & 3) == 0 && w.data && (long long)c.kh * c.kw * c.Ci < 131072) {
                     // int8 MFMA form: the weight panel as int8 (w ^ 0x80) padded to 64-channel tiles, and per channel
                     //   cterm = (128 - zx) sum(w - 128) + K (128 - zx)(128 - zw) + bias   (all exact in int32: |.| < 2^31 for K < 2^17)
                     const int K = c.kh * c.kw * c.Ci, CoPad = (c.Co + 63) / 64 * 64;
-                    std::vector<uint8_t> wq((size_t)CoPad * K, 0x80);   // padding rows: w' = 0
+                    std::vector<uint8_t> wq((size_t)CoPad * K + 16, 0x80);   // padding rows: w' = 0 (+ 16 bytes: the register-fed kernel's last load of a row may reach past it)
                     std::vector<int> ct(CoPad, 0);
                     const int* bias_h = bi >= 0 ? (const int*)T(bi).data : nullptr;
                     for (int o = 0; o < c.Co; ++o) {
@@ -1040,16 +1207,24 @@ int enqueue_plan(yh_tfl* h) {
                     if (p.conv.Ci % 16 == 0) hipLaunchKernelGGL(tfl_conv_u8_dot<4>, grid, dim3(256), 0, s, p.conv);
                     else hipLaunchKernelGGL(tfl_conv_u8_dot<1>, grid, dim3(64), 0, s, p.conv);
                 }
+                else if (h->use_dot && p.conv.kh * p.conv.kw * p.conv.Ci <= kPx8MaxK) {
+                    const dim3 grid((unsigned)(((long long)p.conv.Ho * p.conv.Wo + 255) / 256), (unsigned)((p.conv.Co + 7) / 8), nb);
+                    hipLaunchKernelGGL((tfl_conv_u8_px8<0, 0, 0>), grid, dim3(256), 0, s, p.conv);   // (the <3, 3, 3> form - all 27 input bytes asked for up front - measured 13.0 us against 10.6)
+                }
                 else hipLaunchKernelGGL(tfl_conv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv);
                 break;
             case P_CONV_I8: {
                 ConvI8 q = p.ci8;
                 q.M = q.Ho * q.Wo * (int)nb;
-                if (h->use_dot >= 3) launch_conv_i8_direct(q, s);
+                if (h->use_dot >= 3 && conv_i8_direct_pays(q)) launch_conv_i8_direct(q, s);
                 else hipLaunchKernelGGL(tfl_conv_i8_mfma, dim3((unsigned)((q.M + 63) / 64), (unsigned)((q.Co + 63) / 64)), dim3(256), 0, s, q);
                 break;
             }
-            case P_DW: hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv); break;
+            case P_DW:
+                if (h->use_dot && p.conv.dm == 1 && p.conv.kh == 3 && p.conv.kw == 3 && p.conv.Co % 4 == 0 && (((size_t)p.conv.x | (size_t)p.conv.w) & 3) == 0)
+                    hipLaunchKernelGGL((tfl_dwconv_u8_c4<3, 3>), dim3(nblk((long long)p.conv.Ho * p.conv.Wo * (p.conv.Co >> 2)), nb), dim3(256), 0, s, p.conv);
+                else hipLaunchKernelGGL(tfl_dwconv_u8, dim3(nblk((long long)p.conv.Ho * p.conv.Wo * p.conv.Co), nb), dim3(256), 0, s, p.conv);
+                break;
             case P_ADD: { AddQ q = p.add; q.n *= nb; hipLaunchKernelGGL(tfl_add_u8, dim3(nblk(q.n)), dim3(256), 0, s, q); break; }
             case P_REQUANT: hipLaunchKernelGGL(tfl_requant_u8, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb, p.zi, p.zo, p.m, p.s, p.lo, p.hi); break;
             case P_QUANT_F32: hipLaunchKernelGGL(tfl_quantize_f32, dim3(nblk(p.n * nb)), dim3(256), 0, s, (const float*)p.src, (uint8_t*)p.dst, p.n * nb, p.scale, p.zo); break;
