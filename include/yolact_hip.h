@@ -133,6 +133,11 @@ typedef struct yh_tuning {
                               * second launch. Same bytes (the slabs are summed in slice order in both forms). Measured: 16 launches fewer
                               * at batch 1 and the step SLOWER (0.718 -> 0.896 ms; batch 4: 1.269 -> 1.390) - one workgroup reads a tile's
                               * 8-16 slabs alone where the reduce launch spreads them over the chip */
+    int32_t direct;          /* > 0: f16 1x1 / 3x3 convolutions of 24-36 k-steps and at most this many workgroups of 32 x 32 (layer 4's 1x1
+                              * reductions, lat5, P5-P7 at batch 1 with 192) run on conv_direct_f16 - tiles fed from registers, K split over
+                              * the four waves of a workgroup, no slab and no reduce launch. Default 0 (off): measured neutral per step
+                              * (0.713 vs 0.711 ms at batch 1) and slower on every larger launch (engine.hip, fill_conv_params). Same
+                              * convolution, another summation order (f32): within f16 rounding of the tiled kernels, not bit for bit */
 } yh_tuning;
 
 typedef struct yh_config {

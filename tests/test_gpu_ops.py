@@ -214,7 +214,7 @@ def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
         off += s_ * s_
 
 
-@pytest.mark.parametrize("tile,kslices", [("128x128_S3", 0), ("64x64_S3", 0), ("128x128_S3", 2), ("64x64_S3", 5), ("128x128_S3", -2), ("64x64_S3", -5), ("128x128_M16", 0), ("128x128_S3_M16", 0)])
+@pytest.mark.parametrize("tile,kslices", [("128x128_S3", 0), ("64x64_S3", 0), ("128x128_S3", 2), ("64x64_S3", 5), ("128x128_S3", -2), ("64x64_S3", -5), ("128x128_M16", 0), ("128x128_S3_M16", 0), ("DIRECT32", 0)])
 def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     """The latency-bound tile variants the engine picks at small batch (3-stage 128x128 and 64x64 rings,
     their split-K forms, the 16x16x32 tail tiles), forced through the op entry: ragged M, residual, ReLU."""
@@ -223,7 +223,7 @@ def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     wt = rng.integers(-2, 3, (192, 3, 3, 128)).astype(np.float32)
     b = rng.integers(-4, 5, 192).astype(np.float32)
     r = rng.integers(-5, 6, (2, 13, 11, 192)).astype(np.float32)
-    env = {"op_tile": _TILES[tile]}
+    env = {"op_tile": 26 if tile == "DIRECT32" else _TILES[tile]}   # (26: conv_direct_f16, csrc/conv_direct.hip)
     if kslices: env.update(op_kslices=abs(kslices), splitk_inl=int(kslices < 0))   # (negative: the slabs are summed inside the launch)
     y = _forced(eng, env, lambda: eng.op_conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1))
     assert np.array_equal(y, oracle.conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1, f16=True))

@@ -968,11 +968,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 
 int conv_tile_ch(ConvTile t) {
     switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64;
-                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
+                 case TILE_32x256: case TILE_DIRECT32: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; case TILE_DIRECT32: return 32; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -996,6 +996,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_64x64_FP8: return "conv_igemm_fp8<64,64,2,2>";
         case TILE_128x128_FP8_S3: return "conv_igemm_fp8<128,128,2,2,ring3>";
         case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
+        case TILE_DIRECT32: return "conv_direct_f16<8>";
     }
     return "?";
 }
@@ -1008,6 +1009,7 @@ hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream) {
 
 // One kernel launch (for split-K: the main kernel only).
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
+    if (tile == TILE_DIRECT32) return launch_conv_direct(p, stream);
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm - p.m_tile0;
     if (n_m_tiles < 1) return hipErrorInvalidValue;

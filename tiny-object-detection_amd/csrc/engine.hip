@@ -129,7 +129,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3, splitk_inl;
+        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3, splitk_inl, direct;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -142,7 +142,7 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
-    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0); r.splitk_inl = d(t.splitk_inl, 0);
+    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0); r.splitk_inl = d(t.splitk_inl, 0); r.direct = d(t.direct, 0);
     return r;
 }
 
@@ -979,6 +979,15 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     if (h->tune.ablate & 4) { p.skip_dma = 1; }
     ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
     if (o.dual) tile = dual_conv_tile(tile);
+    // tune.direct (opt-in, measured neutral): the smallest launches of a small-batch step - at most tune.direct workgroups of 32 x 32
+    // and 24-36 k-steps: layer 4's 1x1 reductions, lat5, P5-P7 at batch 1 - on the register-fed tiles of conv_direct.hip: the K split
+    // stays inside the workgroup, there is no slab and no reduce launch. Per launch (event-bracketed, batch 1): those six 12.2-13.6 us
+    // against 13.6-17.4 for the tiled launch + reduce; every larger launch SLOWER (a 312-workgroup layer-3 3x3: 20.5 against 17.0; its
+    // 1x1 neighbours 10.3-12.5 against 7.5-10.5; the 69 x 69 FPN / protonet 3x3: 44 against 20) - a workgroup that streams (32 + 32) x K
+    // operand rows alone is bound by its own memory latency, where the tiled form splits K over six workgroups. The step: 0.7127 ms
+    // with direct = 192, 0.7107 without (batch 2: 0.9365 / 0.9325, batch 4: 1.2739 / 1.2700): not a gain, so the default is off.
+    if (h->tune.direct > 0 && !h->fp8_active && (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && conv_direct_ok(p) && p.ksteps >= 24 && p.ksteps <= 36 &&
+        (long long)((p.M + 31) / 32) * (pn.coutPad / 32) <= h->tune.direct) tile = TILE_DIRECT32;
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
         p.y = o.write_f16 ? o.out.d : nullptr;
@@ -1696,7 +1705,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl;
+    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl; out->direct = t.direct;
     return YH_OK;
 }
 

@@ -99,12 +99,15 @@ struct ConvParams {
 
 // (ids 4 and 9-11 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel - DESIGN.md §4)
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8,
-                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24, TILE_128x128_FP8_S3 = 25 };
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24, TILE_128x128_FP8_S3 = 25,
+                TILE_DIRECT32 = 26 /* conv_direct.hip: 32 x 32 tiles fed from registers, K split over the workgroup's four waves */ };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
 hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream);
+bool conv_direct_ok(const ConvParams& p);                              // conv_direct.hip: TILE_DIRECT32 can run this convolution
+hipError_t launch_conv_direct(const ConvParams& p, hipStream_t stream);
 
 // A bottleneck block's 3x3 conv, its 1x1 expand conv with the residual add, and the NEXT block's 1x1 reduce conv as one
 // kernel (bneck.hip): b stays in LDS, y and a' are written once. planes in {64, 128}.
