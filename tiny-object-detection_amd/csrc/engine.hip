@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -986,7 +987,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     // 1x1 neighbours 10.3-12.5 against 7.5-10.5; the 69 x 69 FPN / protonet 3x3: 44 against 20) - a workgroup that streams (32 + 32) x K
     // operand rows alone is bound by its own memory latency, where the tiled form splits K over six workgroups. The step: 0.7127 ms
     // with direct = 192, 0.7107 without (batch 2: 0.9365 / 0.9325, batch 4: 1.2739 / 1.2700): not a gain, so the default is off.
-    if (h->tune.direct > 0 && !h->fp8_active && (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && conv_direct_ok(p) && p.ksteps >= 24 && p.ksteps <= 36 &&
+    if (h->tune.direct > 0 && !h->fp8_active && (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && conv_direct_ok(p) && ((p.ksteps >= 24 && p.ksteps <= 36) || h->tune.direct >= (1 << 20) /* study: every eligible launch */) &&
         (long long)((p.M + 31) / 32) * (pn.coutPad / 32) <= h->tune.direct) tile = TILE_DIRECT32;
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
@@ -1332,7 +1333,14 @@ int wait_input(yh_engine* h) {
     return YH_OK;
 }
 
+// One capture (and one pinned allocation) at a time in the process. Handles of a group take their first step on threads of their own
+// (group.hip, run_members): a member capturing its step while its neighbour allocated pinned staging memory - both once-only, both
+// deep in the HIP runtime - took the process down with a host segfault in yh_evaluate once in a full test run (never alone). Steady
+// state never comes here: a captured step is replayed, staging buffers are allocated once.
+std::mutex& setup_mutex() { static std::mutex m; return m; }
+
 int capture_step(yh_engine* h, int n, int with_tail, hipGraphExec_t* out) {
+    std::lock_guard<std::mutex> once_only(setup_mutex());
     hipGraph_t g = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
@@ -2046,6 +2054,7 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     if (kind == hipMemcpyHostToDevice && !pinned_src && bytes <= yh_engine::kStageBytes) {
         const int k = h->stage_idx ^= 1;
         if (!h->stage[0]) {
+            std::lock_guard<std::mutex> once_only(setup_mutex());
             // BOTH staging buffers at the first host input: allocated one call apart, the second 4 MB pinned allocation - milliseconds -
             // fell into whatever the caller was timing after its warm-up call
             for (int j = 0; j < 2; ++j) {

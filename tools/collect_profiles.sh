@@ -43,7 +43,14 @@ cp "$(find $OUT/tfl1 -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_tf
 cp "$(find $OUT/tfl0 -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_tflite_unfused_rocprofv3_kernel_stats.csv
 python3 $R/tools/tfl_trace_span.py "$(find $OUT/tfl1 -name "*kernel_trace.csv" | sort | tail -1)" 82 > $OUT/${TAG}_tflite_device_span.txt 2>&1 || true
 python3 $R/tools/tfl_trace_span.py "$(find $OUT/tfl0 -name "*kernel_trace.csv" | sort | tail -1)" 132 >> $OUT/${TAG}_tflite_device_span.txt 2>&1 || true
-{ python3 $R/tools/time_tflite_fuse.py; python3 $R/tools/study/tfl_host_vs_device.py; python3 $R/tools/study/tfl_conv_steps.py; } > $OUT/${TAG}_tflite_timings.txt 2>&1
+{ python3 $R/tools/time_tflite_fuse.py; python3 $R/tools/study/tfl_host_vs_device.py; python3 $R/tools/study/tfl_conv_steps.py 3; python3 $R/tools/study/tfl_conv_steps.py 2; } > $OUT/${TAG}_tflite_timings.txt 2>&1
+# ... the per-launch timeline of the plan (batch-2 invokes) with the register-fed int8 convolutions (tfl_dot = 3, default) and the LDS tiles (2)
+for dot in 3 2; do
+  rocprofv3 --kernel-trace -d $OUT/tl$dot -o run --output-format csv -- python3 $R/tools/study/tfl_layer_run.py tfl_dot=$dot > $OUT/tl$dot.log 2>&1
+  python3 $R/tools/study/tfl_layer_table.py "$(find $OUT/tl$dot -name "*kernel_trace.csv" | sort | tail -1)" 82 > $OUT/${TAG}_tflite_layer_table_dot$dot.txt 2>&1 || true
+done
+# ... and the two batch-1 experiments that stayed opt-in: split-K finished inside the launch, the register-fed f16 convolution
+{ python3 $R/tools/ab_tune.py 1 - splitk_inl=1 direct=192; python3 $R/tools/ab_tune.py 4 - splitk_inl=1 direct=192; python3 $R/tools/study/direct_profile.py 1; } > $OUT/${TAG}_batch1_experiments.txt 2>&1
 { python3 $R/tools/study/xn_forms.py 64; python3 $R/tools/study/xn_forms.py 8 700 101 fp8; } > $OUT/${TAG}_xn_forms.txt 2>&1
 { python3 $R/tools/study/xn2_ablate.py 64 128; python3 $R/tools/study/xn128_ablate.py 64; } > $OUT/${TAG}_xn_ablation.txt 2>&1
 python3 $R/tools/ab_tune_c4.py 8 - fp8_s3=1 > $OUT/${TAG}_ab_fp8_ring3_configs4.txt 2>&1
@@ -59,5 +66,5 @@ echo "[6/6] SQ counters"
     python3 $R/tools/pmc_summary.py "$(find $OUT/pmc_$tag -name "*counter_collection.csv" | sort | tail -1)"
   done
 } > $OUT/${TAG}_pmc_kernels.txt
-rm -rf $OUT/stats $OUT/stats4 $OUT/pmcF $OUT/pmcW $OUT/tfl0 $OUT/tfl1; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
+rm -rf $OUT/stats $OUT/stats4 $OUT/pmcF $OUT/pmcW $OUT/tfl0 $OUT/tfl1 $OUT/tl3 $OUT/tl2; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
 echo done

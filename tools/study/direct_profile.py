@@ -7,7 +7,7 @@ import yolact_amd as ya
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = np.random.default_rng(0).integers(0, 256, (batch, 550, 550, 3), dtype=np.uint8)
 res, blob = {}, None
-for name, tune in (("direct", {}), ("tiled", dict(direct=0))):
+for name, tune in (("direct", dict(direct=1 << 20)), ("tiled", dict(direct=0))):   # (1 << 20: every eligible launch)
     e = ya.Engine(input_size=550, max_batch=batch, use_graph=True, tune=tune)
     if blob is None: blob = e.generate_weights(1)
     e.load_weights(blob); e.set_input(frames)
