@@ -208,7 +208,11 @@ def roofline_of(prof, batch=None):
     r.update(kernel=sym, symbols=d["symbols"], launches=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 5),
              share_of_step=round(d["ms"] / total_ms, 3), algorithmic_gflop_per_launch=round(d["flops"] / d["launches"] / 1e9, 3),
              algorithmic_gbytes_hbm=round(d["bytes"] / 1e9, 4),
-             hbm_gbs_algorithmic=round(gbs, 1), mfma_tflops=round(tf, 2))
+             hbm_gbs_algorithmic=round(gbs, 1), mfma_tflops=round(tf, 2),
+             timing="avg_launch_ms: hipEvent-bracketed launches of the live engine, one kernel on the chip at a time. In the replayed step "
+                    "the head / tail run on a second stream beside the protonet: a kernel trace of the same command (profiles/rNN_rocprofv3_"
+                    "kernel_stats.csv) shows those launches' CONTENDED durations, longer than these by the share of the chip the other stream takes; "
+                    "launches of the backbone phase (one stream) agree with the trace")
     traffic, src = measured_traffic(d["symbols"], batch)
     if traffic is not None:
         r["traffic"] = traffic
