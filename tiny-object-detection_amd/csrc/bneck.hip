@@ -575,10 +575,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
     wg_barrier();
     // whole-row stores of a': k-tiles 2 (tid >> 8) and + 1
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int kt = 2 * (tid >> 8) + k2;
+        // (fp8: the channels' reciprocal scales, once per k-tile - read inside the row loop they were re-loaded behind every store)
+        f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
+        if (p.a_next8) { inv0 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8); inv1 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8 + 4); }
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const int kt = 2 * (tid >> 8) + k2, m = m0 + rb + 32 * d;
+            const int m = m0 + rb + 32 * d;
             if (m < p.M) {
                 const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
                 if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
@@ -586,13 +590,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
                     unsigned lo = 0, hi = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * p.a_next8_inv[kt * 64 + lc * 8 + e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv[kt * 64 + lc * 8 + 4 + e]) << (8 * e);
+                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
                     }
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -808,10 +813,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn128_f16(const BneckParams p) {
     wg_barrier();
     // whole-row stores of a': k-tiles 2 (tid >> 8) and + 1
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int kt = 2 * (tid >> 8) + k2;
+        // (fp8: the channels' reciprocal scales, once per k-tile - read inside the row loop they were re-loaded behind every store)
+        f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
+        if (p.a_next8) { inv0 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8); inv1 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8 + 4); }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int kt = 2 * (tid >> 8) + k2, m = m0 + rb + 32 * d;
+            const int m = m0 + rb + 32 * d;
             if (m < p.M) {
                 const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
                 if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
@@ -819,13 +828,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn128_f16(const BneckParams p) {
                     unsigned lo = 0, hi = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * p.a_next8_inv[kt * 64 + lc * 8 + e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv[kt * 64 + lc * 8 + 4 + e]) << (8 * e);
+                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
                     }
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1042,10 +1052,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn2_f16(const BneckParams p) {
     wg_barrier();
     // whole-row stores of a': all eight waves, k-tiles 2 (tid >> 8) and + 1
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int kt = 2 * (tid >> 8) + k2;
+        // (fp8: the channels' reciprocal scales, once per k-tile - read inside the row loop they were re-loaded behind every store)
+        f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
+        if (p.a_next8) { inv0 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8); inv1 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8 + 4); }
 #pragma unroll
         for (int d = 0; d < RP; ++d) {
-            const int kt = 2 * (tid >> 8) + k2, m = m0 + rb + 32 * d;
+            const int m = m0 + rb + 32 * d;
             if (m < p.M) {
                 const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
                 if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
@@ -1053,13 +1067,14 @@ __global__ __launch_bounds__(512, 1) void bneck_xn2_f16(const BneckParams p) {
                     unsigned lo = 0, hi = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * p.a_next8_inv[kt * 64 + lc * 8 + e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * p.a_next8_inv[kt * 64 + lc * 8 + 4 + e]) << (8 * e);
+                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
+                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
                     }
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }
             }
         }
+    }
 }
 
 const char* bneck_symbol(int planes, int tm, bool next, bool dual) {

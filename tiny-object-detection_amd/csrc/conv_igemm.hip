@@ -590,6 +590,10 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // (fp8 precision, a tensor that feeds an E4M3 convolution: its channels' reciprocal scales, once per tile - read inside the row
+    // loop they were re-loaded behind every store)
+    f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
+    if (p.y8 && ch_ok) { inv0 = *(const f32x4*)(p.y8_inv + ch); inv1 = *(const f32x4*)(p.y8_inv + ch + 4); }
     float scale8[FP8 ? 8 : 1];
     if (FP8) {
         const f32x4 s0 = *(const f32x4*)(p.scale + ch), s1 = *(const f32x4*)(p.scale + ch + 4);
@@ -711,11 +715,10 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     if (p.y) *(half8*)(p.y + yo) = o;
                     if (p.y8) {   // fp8 precision: this tensor feeds an fp8 convolution (quantised from the f16-rounded value)
                         unsigned lo = 0, hi = 0;
-                        const f32x4 i0 = *(const f32x4*)(p.y8_inv + ch), i1 = *(const f32x4*)(p.y8_inv + ch + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            lo |= e4m3_code((float)o[e] * i0[e]) << (8 * e);
-                            hi |= e4m3_code((float)o[4 + e] * i1[e]) << (8 * e);
+                            lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
+                            hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
                         }
                         *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
                     }
