@@ -138,6 +138,9 @@ typedef struct yh_tuning {
                               * the four waves of a workgroup, no slab and no reduce launch. Default 0 (off): measured neutral per step
                               * (0.713 vs 0.711 ms at batch 1) and slower on every larger launch (engine.hip, fill_conv_params). Same
                               * convolution, another summation order (f32): within f16 rounding of the tiled kernels, not bit for bit */
+    int32_t tfl_group;       /* TFLite path: 1 (default) independent register-fed convolutions of one kernel form at one depth of the plan's
+                              * graph as ONE launch (the prediction head's convolutions over the pyramid levels: 23 launches become 3), the
+                              * plan in depth order; 0: one launch per convolution in file order. Same bytes. Only with tfl_streams = 1 */
 } yh_tuning;
 
 typedef struct yh_config {

@@ -83,7 +83,9 @@ def test_operator_fusion_keeps_every_surviving_tensor_bit_exact(built):
     Bit-exactness against the numpy oracle on every tensor the fused plan still writes (the 40-op graph: conv -> ADD -> RELU,
     resize -> nothing (its ADD's other producer runs later), conv -> TANH with two readers, conv -> QUANTIZE -> RESHAPE -> output;
     the 136-op stand-in: 9 residual ADDs, 2 FPN ADDs, 2 PADs, 5 TANH + 16 QUANTIZE chains into 3 CONCATENATIONs) and equality with
-    the unfused plan (tfl_fuse = 0, the checker) on every output; launch counts from yh_tfl_plan_info."""
+    the unfused plan (tfl_fuse = 0, the checker) on every output; launch counts from yh_tfl_plan_info. The fused engine also runs
+    yh_tuning.tfl_group (default): the plan in depth order with the independent register-fed convolutions of one kernel form as one
+    launch (the head's convolutions over the five pyramid levels) - the checker does neither, so equality here covers both."""
     import yolact_amd as ya
     rng = np.random.default_rng(7)
     small = M.mobilenet_like(rng, S=64, C=6)
@@ -100,10 +102,10 @@ def test_operator_fusion_keeps_every_surviving_tensor_bit_exact(built):
     x = rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8)
     import tfl_oracle as TO
     vals = [TO.run_model(big, {big.inputs[0]: x[i:i + 1]}) for i in range(2)]
-    fused, plain = ya.TfliteEngine(blob), ya.TfliteEngine(blob, tune=dict(tfl_fuse=0))
+    fused, plain = ya.TfliteEngine(blob), ya.TfliteEngine(blob, tune=dict(tfl_fuse=0, tfl_group=0))   # (plain: one launch per operator, in file order)
     pf, pp = fused.plan_summary(), plain.plan_summary()
     print("fused plan:", pf, " unfused:", pp)
-    assert pp["launches_per_invoke"] >= 130 and pf["launches_per_invoke"] <= 85, (pf, pp)
+    assert pp["launches_per_invoke"] >= 130 and pf["launches_per_invoke"] <= 60, (pf, pp)   # (82 after operator fusion, 58 with the independent convolutions grouped)
     assert pf["conv2d_launches"] == pp["conv2d_launches"] == 64
     for e in (fused, plain):
         e.set_batch(2); e.set_input(x); e.invoke()

@@ -1713,7 +1713,7 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl; out->direct = t.direct;
+    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->tfl_group = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl; out->direct = t.direct;
     return YH_OK;
 }
 

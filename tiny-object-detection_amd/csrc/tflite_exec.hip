@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -406,10 +407,10 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
 // KK (ONCE only): the kernel extent, 1 x 1 or 3 x 3 - the tap and the channel chunk of step d are then compile-time constants and
 // the position bookkeeping below disappears from the prologue (0: run-time extent, looped form).
 template <int D, bool ONCE, int KK>
-__global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
+__device__ __forceinline__ void conv_i8_direct_tile(const ConvI8& p, int tile_m, int tile_c) {
     static_assert(KK == 0 || (ONCE && D % (KK * KK) == 0), "compile-time extents: the launch's k-steps are exactly D");
     const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.x * 16, ch0 = blockIdx.y * 16;
+    const int m0 = tile_m * 16, ch0 = tile_c * 16;
     const int HoWo = p.Ho * p.Wo;
     const int m = m0 + l15;
     const bool live = m < p.M;
@@ -482,6 +483,24 @@ __global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
     sx[0] += __shfl_xor(sx[0], 32);
     conv_i8_epilogue<1, 1>(p, acc, sx, m0, ch0, 0, 0, l15, lg, HoWo);
 }
+template <int D, bool ONCE, int KK>
+__global__ __launch_bounds__(64) void tfl_conv_i8_direct(const ConvI8 p) {
+    conv_i8_direct_tile<D, ONCE, KK>(p, blockIdx.x, blockIdx.y);
+}
+// Several INDEPENDENT convolutions of one kernel form as ONE launch (yh_tuning.tfl_group; group_plan): the prediction head's
+// tower convolutions of the five pyramid levels, then its fifteen output convolutions, the FPN's output convolutions. The
+// problems' parameter blocks sit in device memory; a workgroup finds its problem in the tile prefix table (at most kMaxGroup
+// entries, wave-uniform) and runs the same tile code on it.
+constexpr int kMaxGroup = 16;
+template <int D, bool ONCE, int KK>
+__global__ __launch_bounds__(64) void tfl_conv_i8_direct_group(const ConvI8* __restrict__ probs, const int* __restrict__ tile_start, int nprob) {
+    const int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < nprob; ++i) pi = bid >= tile_start[i] ? i : pi;
+    const ConvI8 p = probs[pi];
+    const int t = bid - tile_start[pi], mtiles = (p.M + 15) >> 4;
+    conv_i8_direct_tile<D, ONCE, KK>(p, t % mtiles, t / mtiles);
+}
 // The ring depth for a launch of n k-steps: n itself where a kernel of that depth exists (ONCE), else the D of {9 8 6 5 4} that
 // pads n least, the deepest among equals.
 static int conv_i8_direct_depth(int n, bool* once) {
@@ -493,43 +512,44 @@ static int conv_i8_direct_depth(int n, bool* once) {
     for (int d : ds) { if (d > n) continue; const int q = (n + d - 1) / d * d - n; if (q < pad) { pad = q; best = d; } }
     return best;
 }
+// One launch of the register-fed kernel: a single convolution (probs == nullptr) or a group of them (device arrays, `tiles` workgroups)
+struct DirectLaunch { const ConvI8* q; const ConvI8* probs; const int* tile_start; int nprob; int tiles; };
 template <int D, bool ONCE, int KK>
-static void launch_conv_i8_direct_d(const ConvI8& q, hipStream_t s) {
-    hipLaunchKernelGGL((tfl_conv_i8_direct<D, ONCE, KK>), dim3((unsigned)((q.M + 15) / 16), (unsigned)((q.Co + 15) / 16)), dim3(64), 0, s, q);
+static void launch_conv_i8_direct_d(const DirectLaunch& L, hipStream_t s) {
+    if (L.probs) hipLaunchKernelGGL((tfl_conv_i8_direct_group<D, ONCE, KK>), dim3((unsigned)L.tiles), dim3(64), 0, s, L.probs, L.tile_start, L.nprob);
+    else hipLaunchKernelGGL((tfl_conv_i8_direct<D, ONCE, KK>), dim3((unsigned)((L.q->M + 15) / 16), (unsigned)((L.q->Co + 15) / 16)), dim3(64), 0, s, *L.q);
 }
-static void launch_conv_i8_direct(const ConvI8& q, hipStream_t s) {
+// The kernel form of a convolution: (D, ONCE, KK) packed into one int (convolutions of one group share it)
+static int conv_i8_direct_form(const ConvI8& q) {
     bool once = false;
     const int n = q.kh * q.kw * ((q.Ci + 63) / 64);
     int d = conv_i8_direct_depth(n, &once);
     const int kk = q.kh == 1 && q.kw == 1 ? 1 : (q.kh == 3 && q.kw == 3 ? 3 : 0);
-    if (once && kk == 3 && (d == 9 || d == 18)) {
-        if (d == 9) launch_conv_i8_direct_d<9, true, 3>(q, s); else launch_conv_i8_direct_d<18, true, 3>(q, s);
-        return;
-    }
-    if (once && kk == 1) {
-        switch (d) {
-            case 1: launch_conv_i8_direct_d<1, true, 1>(q, s); break;
-            case 2: launch_conv_i8_direct_d<2, true, 1>(q, s); break;
-            case 3: launch_conv_i8_direct_d<3, true, 1>(q, s); break;
-            case 4: launch_conv_i8_direct_d<4, true, 1>(q, s); break;
-            case 5: launch_conv_i8_direct_d<5, true, 1>(q, s); break;
-            case 6: launch_conv_i8_direct_d<6, true, 1>(q, s); break;
-            case 8: launch_conv_i8_direct_d<8, true, 1>(q, s); break;
-            case 9: launch_conv_i8_direct_d<9, true, 1>(q, s); break;
-            case 12: launch_conv_i8_direct_d<12, true, 1>(q, s); break;
-            case 15: launch_conv_i8_direct_d<15, true, 1>(q, s); break;
-            default: launch_conv_i8_direct_d<18, true, 1>(q, s); break;
-        }
-        return;
-    }
-    // any other extent (or step count): the looped form
-    if (once) { d = n >= 9 ? 9 : (n >= 8 ? 8 : (n >= 6 ? 6 : (n >= 5 ? 5 : 4))); }
-    switch (d) {
-        case 4: launch_conv_i8_direct_d<4, false, 0>(q, s); break;
-        case 5: launch_conv_i8_direct_d<5, false, 0>(q, s); break;
-        case 6: launch_conv_i8_direct_d<6, false, 0>(q, s); break;
-        case 8: launch_conv_i8_direct_d<8, false, 0>(q, s); break;
-        default: launch_conv_i8_direct_d<9, false, 0>(q, s); break;
+    if (once && kk == 3 && (d == 9 || d == 18)) return d * 16 + 8 + 3;
+    if (once && kk == 1) return d * 16 + 8 + 1;
+    if (once) d = n >= 9 ? 9 : (n >= 8 ? 8 : (n >= 6 ? 6 : (n >= 5 ? 5 : 4)));   // any other extent (or step count): the looped form
+    return d * 16;
+}
+static void launch_conv_i8_direct(const DirectLaunch& L, hipStream_t s) {
+    switch (conv_i8_direct_form(*L.q)) {
+        case 9 * 16 + 8 + 3: launch_conv_i8_direct_d<9, true, 3>(L, s); break;
+        case 18 * 16 + 8 + 3: launch_conv_i8_direct_d<18, true, 3>(L, s); break;
+        case 1 * 16 + 8 + 1: launch_conv_i8_direct_d<1, true, 1>(L, s); break;
+        case 2 * 16 + 8 + 1: launch_conv_i8_direct_d<2, true, 1>(L, s); break;
+        case 3 * 16 + 8 + 1: launch_conv_i8_direct_d<3, true, 1>(L, s); break;
+        case 4 * 16 + 8 + 1: launch_conv_i8_direct_d<4, true, 1>(L, s); break;
+        case 5 * 16 + 8 + 1: launch_conv_i8_direct_d<5, true, 1>(L, s); break;
+        case 6 * 16 + 8 + 1: launch_conv_i8_direct_d<6, true, 1>(L, s); break;
+        case 8 * 16 + 8 + 1: launch_conv_i8_direct_d<8, true, 1>(L, s); break;
+        case 9 * 16 + 8 + 1: launch_conv_i8_direct_d<9, true, 1>(L, s); break;
+        case 12 * 16 + 8 + 1: launch_conv_i8_direct_d<12, true, 1>(L, s); break;
+        case 15 * 16 + 8 + 1: launch_conv_i8_direct_d<15, true, 1>(L, s); break;
+        case 18 * 16 + 8 + 1: launch_conv_i8_direct_d<18, true, 1>(L, s); break;
+        case 4 * 16: launch_conv_i8_direct_d<4, false, 0>(L, s); break;
+        case 5 * 16: launch_conv_i8_direct_d<5, false, 0>(L, s); break;
+        case 6 * 16: launch_conv_i8_direct_d<6, false, 0>(L, s); break;
+        case 8 * 16: launch_conv_i8_direct_d<8, false, 0>(L, s); break;
+        default: launch_conv_i8_direct_d<9, false, 0>(L, s); break;
     }
 }
 // Which int8 MFMA launches take the register-fed kernel: every one whose input channels the LDS tiles cannot take (Ci % 64 != 0), and
@@ -732,6 +752,7 @@ struct Prepared {
     int lane = 0;        // stream it is launched on (schedule_plan); 0 = the handle's own stream
     std::vector<int> waits;   // plan entries on OTHER lanes whose completion it waits for (their events)
     bool signal = false;      // an entry on another lane waits for it: record its event behind the launch
+    int group = -1;           // >= 0: this convolution is launched as part of h->groups[group] (group_plan), by the group's first member
     ConvQ conv; ConvI8 ci8; AddQ add; PadQ pad; ResizeQ rs;
     std::vector<CatQ> cat;
     const void* src = nullptr; void* dst = nullptr; long long n = 0;
@@ -765,6 +786,12 @@ struct yh_tfl {
     std::vector<hipEvent_t> pev;      // per plan entry (created for the signalling ones)
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> ev_end;   // per side lane
+    // yh_tuning.tfl_group (round 4): independent register-fed convolutions of one kernel form and one depth of the plan's DAG as ONE
+    // launch (group_plan); `order` is the plan in execution order (by depth; the identity when nothing is grouped)
+    struct ConvGroup { std::vector<int> members; const ConvI8* probs[kMaxBatch] = { nullptr, nullptr }; const int* tile_start[kMaxBatch] = { nullptr, nullptr }; int tiles[kMaxBatch] = { 0, 0 }; };
+    int use_group = 1;
+    std::vector<ConvGroup> groups;
+    std::vector<int> order;
     int use_fuse = 1;                 // yh_tuning.tfl_fuse: element-wise operators / PAD / CONCATENATION parts folded into their producers (fuse_plan)
     std::vector<char> gone;           // tensor i is never written by the fused plan (yh_tfl_tensor_read says so)
     int use_dot = 3, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel on LDS tiles where Ci % 64 == 0, 3 + its register-fed form where Ci % 16 == 0: default) / tfl_graph
@@ -1115,6 +1142,113 @@ void fuse_plan(yh_tfl* h) {
     }
 }
 
+// What a plan entry reads and writes (device pointers into the tensors' allocations).
+static void entry_io(const Prepared& p, std::vector<const void*>& rd, std::vector<const void*>& wr) {
+    switch (p.kind) {
+        case P_CONV: case P_DW: rd.push_back(p.conv.x); wr.push_back(p.conv.y); if (p.conv.po.other) rd.push_back(p.conv.po.other); break;
+        case P_CONV_I8: rd.push_back(p.ci8.x); wr.push_back(p.ci8.y); if (p.ci8.po.other) rd.push_back(p.ci8.po.other); break;
+        case P_ADD: rd.push_back(p.add.a); rd.push_back(p.add.b); wr.push_back(p.add.y); break;
+        case P_PAD: rd.push_back(p.pad.x); wr.push_back(p.pad.y); break;
+        case P_RESIZE: rd.push_back(p.rs.x); wr.push_back(p.rs.y); if (p.rs.po.other) rd.push_back(p.rs.po.other); break;
+        case P_CONCAT: for (const CatQ& c : p.cat) { rd.push_back(c.x); wr.push_back(c.y); } break;
+        default: rd.push_back(p.src); wr.push_back(p.dst); break;
+    }
+}
+
+// yh_tuning.tfl_group: the plan is a DAG, and on this part a dependent launch costs 4.4 us however little it does - so independent
+// convolutions that run the same register-fed kernel are launched TOGETHER. Every live entry gets its depth (longest chain of
+// producers in front of it: an entry depends on the earlier writers of what it reads and, conservatively, on the earlier readers and
+// writers of what it writes); the plan runs in depth order, which is a topological order; within a depth, the register-fed
+// convolutions of one kernel form (same extent and k-steps) become one launch of tfl_conv_i8_direct_group with their parameter blocks in
+// device memory. The 136-op model: the five levels' tower convolutions, their fifteen output convolutions and the FPN's three output
+// convolutions are three launches instead of twenty-three. Same kernels on the same operands: same bytes.
+int group_plan(yh_tfl* h) {
+    struct Range { const char* lo; const char* hi; };
+    std::vector<Range> al;
+    for (size_t i = 0; i < h->tens.size(); ++i)
+        if (h->tens[i] && !h->alias[i]) {
+            const TflTensor& t = h->m.tensors[i];
+            const size_t bytes = t.count() * t.elem();
+            al.push_back(Range{ (const char*)h->tens[i], (const char*)h->tens[i] + (t.data ? bytes : bytes * yh_tfl::kMaxBatch) + 16 });
+        }
+    auto alloc_of = [&](const void* q) -> int {
+        for (size_t i = 0; i < al.size(); ++i) if ((const char*)q >= al[i].lo && (const char*)q < al[i].hi) return (int)i;
+        return -1;
+    };
+    const int np = (int)h->plan.size();
+    std::vector<std::vector<int>> writers(al.size()), readers(al.size());
+    std::vector<int> depth((size_t)np, 0);
+    for (int i = 0; i < np; ++i) {
+        const Prepared& p = h->plan[i];
+        if (p.dead) continue;
+        std::vector<const void*> rd, wr;
+        entry_io(p, rd, wr);
+        int dmax = 0;
+        for (const void* q : rd) { const int a = alloc_of(q); if (a >= 0) for (int w : writers[a]) dmax = std::max(dmax, depth[w] + 1); }
+        for (const void* q : wr) {
+            const int a = alloc_of(q);
+            if (a < 0) continue;
+            for (int r : readers[a]) if (r != i) dmax = std::max(dmax, depth[r] + 1);
+            // (writers of other PARTS of one allocation - CONCATENATION parts written in place - are independent of each other; a writer of the
+            // same bytes is not)
+            for (int w : writers[a]) {
+                std::vector<const void*> r2, w2;
+                entry_io(h->plan[w], r2, w2);
+                for (const void* q2 : w2) if (q2 == q) dmax = std::max(dmax, depth[w] + 1);
+            }
+        }
+        depth[i] = dmax;
+        for (const void* q : rd) { const int a = alloc_of(q); if (a >= 0) readers[a].push_back(i); }
+        for (const void* q : wr) { const int a = alloc_of(q); if (a >= 0) writers[a].push_back(i); }
+    }
+    h->order.clear();
+    for (int i = 0; i < np; ++i) if (!h->plan[i].dead) h->order.push_back(i);
+    std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+    // groups: consecutive runs of one depth in `order`, bucketed by kernel form
+    auto candidate = [&](const Prepared& p) {
+        if (p.kind != P_CONV_I8 || h->use_dot < 3) return false;
+        ConvI8 q = p.ci8;
+        q.M = q.Ho * q.Wo * yh_tfl::kMaxBatch;
+        return conv_i8_direct_pays(q);
+    };
+    for (size_t a = 0; a < h->order.size();) {
+        size_t b = a;
+        while (b < h->order.size() && depth[h->order[b]] == depth[h->order[a]]) ++b;
+        std::map<int, std::vector<int>> byform;
+        for (size_t k = a; k < b; ++k) { const Prepared& p = h->plan[h->order[k]]; if (candidate(p)) byform[conv_i8_direct_form(p.ci8)].push_back(h->order[k]); }
+        for (auto& kv : byform) {
+            std::vector<int>& v = kv.second;
+            for (size_t c0 = 0; c0 + 1 < v.size(); c0 += kMaxGroup) {
+                const size_t c1 = std::min(v.size(), c0 + (size_t)kMaxGroup);
+                if (c1 - c0 < 2) break;
+                yh_tfl::ConvGroup g;
+                g.members.assign(v.begin() + c0, v.begin() + c1);
+                for (int nb = 1; nb <= yh_tfl::kMaxBatch; ++nb) {
+                    std::vector<ConvI8> probs;
+                    std::vector<int> start(1, 0);
+                    for (int mi : g.members) {
+                        ConvI8 q = h->plan[mi].ci8;
+                        q.M = q.Ho * q.Wo * nb;
+                        probs.push_back(q);
+                        start.push_back(start.back() + ((q.M + 15) / 16) * ((q.Co + 15) / 16));
+                    }
+                    void *dp = nullptr, *ds = nullptr;
+                    if (hipMalloc(&dp, probs.size() * sizeof(ConvI8)) != hipSuccess || hipMalloc(&ds, start.size() * sizeof(int)) != hipSuccess) return h->fail(YH_ENOMEM, "hipMalloc conv group");
+                    h->extra.push_back(dp); h->extra.push_back(ds);
+                    if (hipMemcpy(dp, probs.data(), probs.size() * sizeof(ConvI8), hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(ds, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return h->fail(YH_EHIP, "conv group upload");
+                    g.probs[nb - 1] = (const ConvI8*)dp; g.tile_start[nb - 1] = (const int*)ds; g.tiles[nb - 1] = start.back();
+                }
+                for (int mi : g.members) h->plan[mi].group = (int)h->groups.size();
+                h->groups.push_back(g);
+            }
+        }
+        a = b;
+    }
+    return YH_OK;
+}
+
+
 // Static list scheduling of the (fused) plan onto the lanes. What an entry reads and writes is taken from its final device pointers
 // (after fusion an output may live inside a CONCATENATION's buffer), resolved to the allocation that holds them; an entry depends on
 // every earlier entry that wrote an allocation it reads (tensors are written once per invoke; the parts of a concatenation are
@@ -1191,9 +1325,11 @@ int enqueue_plan(yh_tfl* h) {
     }
     const unsigned nb = (unsigned)h->nb;   // images of this invoke: activations are image-major, so element-wise ops just see nb x the elements
     TraceRange tr_all("yh_tfl:plan(enqueue)");
-    for (size_t pi = 0; pi < h->plan.size(); ++pi) {
+    for (size_t oi = 0; oi < h->order.size(); ++oi) {
+        const size_t pi = (size_t)h->order[oi];   // (execution order: by depth of the plan's DAG where convolutions are grouped, else the file's)
         const Prepared& p = h->plan[pi];
         if (p.dead) continue;   // folded into another launch (fuse_plan)
+        if (p.group >= 0 && h->groups[p.group].members[0] != (int)pi) continue;   // launched with its group's first member
         if (multi) {
             s = h->lanes[p.lane];
             for (int d : p.waits) TCHK(h, hipStreamWaitEvent(s, h->pev[d], 0));
@@ -1216,7 +1352,11 @@ int enqueue_plan(yh_tfl* h) {
             case P_CONV_I8: {
                 ConvI8 q = p.ci8;
                 q.M = q.Ho * q.Wo * (int)nb;
-                if (h->use_dot >= 3 && conv_i8_direct_pays(q)) launch_conv_i8_direct(q, s);
+                if (p.group >= 0) {
+                    const yh_tfl::ConvGroup& g = h->groups[p.group];
+                    launch_conv_i8_direct(DirectLaunch{ &q, g.probs[nb - 1], g.tile_start[nb - 1], (int)g.members.size(), g.tiles[nb - 1] }, s);
+                }
+                else if (h->use_dot >= 3 && conv_i8_direct_pays(q)) launch_conv_i8_direct(DirectLaunch{ &q, nullptr, nullptr, 0, 0 }, s);
                 else hipLaunchKernelGGL(tfl_conv_i8_mfma, dim3((unsigned)((q.M + 63) / 64), (unsigned)((q.Co + 63) / 64)), dim3(256), 0, s, q);
                 break;
             }
@@ -1330,6 +1470,7 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     if (tune && tune->tfl_dot >= 0) h->use_dot = tune->tfl_dot;
     if (tune && tune->tfl_graph >= 0) h->use_graph = tune->tfl_graph;
     if (tune && tune->tfl_fuse >= 0) h->use_fuse = tune->tfl_fuse;
+    if (tune && tune->tfl_group >= 0) h->use_group = tune->tfl_group;
     if (tune && tune->tfl_streams >= 1) h->n_lanes = tune->tfl_streams > 8 ? 8 : tune->tfl_streams;
     // The captured form keeps one lane: capturing the 4-lane plan (some 80 cross-stream event edges) took the process down
     // inside the HIP runtime on ROCm 7.2 (a host segfault in the invoke that captures), and the graph form is the slower,
@@ -1346,6 +1487,8 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     if (rc) return bail(rc);
     h->gone.assign(h->m.tensors.size(), 0);
     if (h->use_fuse) fuse_plan(h);
+    for (int i = 0; i < (int)h->plan.size(); ++i) h->order.push_back(i);
+    if (h->use_group && h->n_lanes == 1 && (rc = group_plan(h))) return bail(rc);
     h->lanes.assign(1, h->stream);
     h->ev_end.assign((size_t)h->n_lanes, nullptr);
     for (int l = 1; l < h->n_lanes; ++l) {
@@ -1363,8 +1506,10 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
 int yh_tfl_plan_info(const yh_tfl* h, int32_t* launches, int32_t* conv_launches, int32_t* conv_mfma_launches) {
     if (!h) return YH_EINVAL;
     int n = 0, nc = 0, nm = 0;
-    for (const Prepared& p : h->plan) {
+    for (size_t i = 0; i < h->plan.size(); ++i) {
+        const Prepared& p = h->plan[i];
         if (p.dead) continue;
+        if (p.group >= 0 && h->groups[p.group].members[0] != (int)i) { ++nc; ++nm; continue; }   // (a convolution launched with its group)
         n += p.kind == P_CONCAT ? (int)p.cat.size() : 1;
         if (p.kind == P_CONV || p.kind == P_CONV_I8) ++nc;
         if (p.kind == P_CONV_I8) ++nm;

@@ -22,7 +22,7 @@ PRECISION_F16, PRECISION_FP8 = 0, 1
 # yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
 TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
                  "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
-                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "xn_tm", "xn_pipe", "fp8_s3", "tfl_fuse", "tfl_streams", "splitk_inl", "direct")
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "xn_tm", "xn_pipe", "fp8_s3", "tfl_fuse", "tfl_streams", "splitk_inl", "direct", "tfl_group")
 
 
 class Tuning(C.Structure):

@@ -37,17 +37,17 @@ python3 $R/tools/ab_chain.py 64 0 1 65 > $OUT/${TAG}_ab_chain.txt 2>&1
 # round 4: the .tflite executor under the profiler (fused plan and one launch per operator), its fused / unfused / graph timings,
 # the cost model of one int8-MFMA conv launch; layer 3's expand + next-reduce launch in all five forms, and the ablation of the pipelined one
 for f in 1 0; do
-  rocprofv3 --kernel-trace --stats -d $OUT/tfl$f -o run --output-format csv -- python3 $R/tools/time_tflite_fuse.py fuse=$f,graph=0 > $OUT/tfl$f.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/tfl$f -o run --output-format csv -- python3 $R/tools/time_tflite_fuse.py fuse=$f,graph=0,group=$f > $OUT/tfl$f.log 2>&1
 done
 cp "$(find $OUT/tfl1 -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_tflite_rocprofv3_kernel_stats.csv
 cp "$(find $OUT/tfl0 -name "*kernel_stats.csv" | sort | tail -1)" $OUT/${TAG}_tflite_unfused_rocprofv3_kernel_stats.csv
-python3 $R/tools/tfl_trace_span.py "$(find $OUT/tfl1 -name "*kernel_trace.csv" | sort | tail -1)" 82 > $OUT/${TAG}_tflite_device_span.txt 2>&1 || true
+python3 $R/tools/tfl_trace_span.py "$(find $OUT/tfl1 -name "*kernel_trace.csv" | sort | tail -1)" 58 > $OUT/${TAG}_tflite_device_span.txt 2>&1 || true
 python3 $R/tools/tfl_trace_span.py "$(find $OUT/tfl0 -name "*kernel_trace.csv" | sort | tail -1)" 132 >> $OUT/${TAG}_tflite_device_span.txt 2>&1 || true
 { python3 $R/tools/time_tflite_fuse.py; python3 $R/tools/study/tfl_host_vs_device.py; python3 $R/tools/study/tfl_conv_steps.py 3; python3 $R/tools/study/tfl_conv_steps.py 2; } > $OUT/${TAG}_tflite_timings.txt 2>&1
 # ... the per-launch timeline of the plan (batch-2 invokes) with the register-fed int8 convolutions (tfl_dot = 3, default) and the LDS tiles (2)
 for dot in 3 2; do
-  rocprofv3 --kernel-trace -d $OUT/tl$dot -o run --output-format csv -- python3 $R/tools/study/tfl_layer_run.py tfl_dot=$dot > $OUT/tl$dot.log 2>&1
-  python3 $R/tools/study/tfl_layer_table.py "$(find $OUT/tl$dot -name "*kernel_trace.csv" | sort | tail -1)" 82 > $OUT/${TAG}_tflite_layer_table_dot$dot.txt 2>&1 || true
+  rocprofv3 --kernel-trace -d $OUT/tl$dot -o run --output-format csv -- python3 $R/tools/study/tfl_layer_run.py tfl_dot=$dot,tfl_group=$((dot == 3)) > $OUT/tl$dot.log 2>&1
+  python3 $R/tools/study/tfl_layer_table.py "$(find $OUT/tl$dot -name "*kernel_trace.csv" | sort | tail -1)" "$(grep LAUNCHES $OUT/tl$dot.log | cut -d' ' -f2)" > $OUT/${TAG}_tflite_layer_table_dot$dot.txt 2>&1 || true
 done
 # ... and the two batch-1 experiments that stayed opt-in: split-K finished inside the launch, the register-fed f16 convolution
 { python3 $R/tools/ab_tune.py 1 - splitk_inl=1 direct=192; python3 $R/tools/ab_tune.py 4 - splitk_inl=1 direct=192; python3 $R/tools/study/direct_profile.py 1; } > $OUT/${TAG}_batch1_experiments.txt 2>&1

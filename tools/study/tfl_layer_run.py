@@ -13,7 +13,9 @@ e = ya.TfliteEngine(bytes(B.serialize(M.mobilenetv2_yolact(rng))), tune=tune)
 x = rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8)
 e.set_batch(2)
 e.set_input(x)
-print(e.plan_summary(), flush=True)
+ps = e.plan_summary()
+print(ps, flush=True)
+print("LAUNCHES", ps["launches_per_invoke"], flush=True)
 for _ in range(300):
     e.invoke()
 e.output(4)
