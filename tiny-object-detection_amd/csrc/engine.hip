@@ -988,10 +988,7 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     // operand rows alone is bound by its own memory latency, where the tiled form splits K over six workgroups. The step: 0.7127 ms
     // with direct = 192, 0.7107 without (batch 2: 0.9365 / 0.9325, batch 4: 1.2739 / 1.2700): not a gain, so the default is off.
     if (h->tune.direct > 0 && !h->fp8_active && (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && conv_direct_ok(p) && ((p.ksteps >= 24 && p.ksteps <= 36) || h->tune.direct >= (1 << 20) /* study: every eligible launch */) &&
-        (long long)((p.M + 31) / 32) * (pn.coutPad / 32) <= h->tune.direct) {
-        tile = TILE_DIRECT32;
-        p.k1steps = (h->tune.ablate >> 12) & 3;   // (study: conv_direct.hip's form override - bit 0 two rings, bit 1 one wave per tile)
-    }
+        (long long)((p.M + 31) / 32) * (pn.coutPad / 32) <= h->tune.direct) tile = TILE_DIRECT32;
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
         p.y = o.write_f16 ? o.out.d : nullptr;
