@@ -125,6 +125,38 @@ def test_operator_fusion_keeps_every_surviving_tensor_bit_exact(built):
     fused.close(); plain.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_branchy_graphs_fused_grouped_and_plain_plans_agree(built, seed):
+    """Random DAGs (tests/tfl_models.random_dag: independent convolutions of equal shape at one depth, diamonds, ADDs of branches,
+    CONCATENATIONs with and without in-place parts, element-wise chains): the default plan - operators folded into their producers,
+    depth order, independent register-fed convolutions of one form as one launch - against the numpy oracle on every output and
+    every tensor the plan still writes, and against the plain plan (one launch per operator, file order) on every output; one and
+    two images per invoke. A wrong dependency in the reordering, a group member launched before its producer or a folded
+    operator applied twice would show here."""
+    import tfl_oracle as O
+    import yolact_amd as ya
+    rng = np.random.default_rng(1000 + seed)
+    model = M.random_dag(rng, n_ops=36 + 2 * seed)
+    blob = bytes(B.serialize(model))
+    x = rng.integers(0, 256, (2, 9, 7, 16), dtype=np.uint8)
+    vals = [O.run_model(model, {model.inputs[0]: x[i:i + 1]}) for i in range(2)]
+    fast, plain = ya.TfliteEngine(blob), ya.TfliteEngine(blob, tune=dict(tfl_fuse=0, tfl_group=0))
+    nogroup = ya.TfliteEngine(blob, tune=dict(tfl_group=0))
+    lf, lp, ln = (e.plan_summary()["launches_per_invoke"] for e in (fast, plain, nogroup))
+    assert lf <= ln <= lp, (lf, ln, lp)
+    for nb in (2, 1):
+        for e in (fast, plain):
+            e.set_batch(nb); e.set_input(x[:nb]); e.invoke()
+        for k, o in enumerate(model.outputs):
+            a, b = fast.output(k), plain.output(k)
+            assert np.array_equal(a, b), (seed, nb, model.tensors[o].name)
+            for i in range(nb):
+                assert np.array_equal(np.asarray(a).reshape((nb,) + tuple(np.asarray(vals[i][o]).shape[1:]))[i], np.asarray(vals[i][o])[0]), (seed, nb, model.tensors[o].name, i)
+    _surviving(fast, model, vals[0], ya)    # (batch 1 was the last invoke)
+    for e in (fast, plain, nogroup): e.close()
+    print(f"seed {seed}: {lp} launches plain, {ln} fused, {lf} fused + grouped")
+
+
 def test_mobilenet_like_graph_every_tensor(built):
     """Every activation of a 40-op MobileNetV2-FPN-shaped graph, not only the outputs (one launch per operator: tfl_fuse = 0)."""
     rng = np.random.default_rng(7)

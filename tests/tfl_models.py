@@ -264,3 +264,74 @@ def mobilenetv2_yolact(rng, S=224, C=81, fpn=128, nproto=32):
     m.inputs = [x]
     m.outputs = [outs[0], outs[1], outs[2], proto, cells]
     return m
+
+
+def random_dag(rng, n_ops=36, hw=(9, 7)):
+    """A random branchy uint8 graph for the plan-level transformations (operator fusion, depth ordering, grouped launches): every
+    new operator reads tensors picked at random among those that exist, so independent convolutions of equal shape at one depth,
+    diamonds, ADDs of branches, CONCATENATIONs whose parts have (sometimes) the output's own quantisation, and chains of
+    element-wise operators all occur. Outputs: every tensor nobody reads, plus a few that somebody does."""
+    m = Model()
+    H, W = hw
+    sc = lambda: float(rng.uniform(0.02, 0.08))
+    zp = lambda: int(rng.integers(90, 160))
+    x = m.add(T("input", (1, H, W, 16), "u8", scale=1 / 128, zp=128))
+    avail = [(x, 16)]          # (tensor index, channels); all are [1, H, W, c]
+    readers = {x: 0}
+
+    def new(name, c, scale=None, z=None):
+        t = m.add(T(f"{name}{len(m.tensors)}", (1, H, W, c), "u8", scale=scale or sc(), zp=zp() if z is None else z))
+        avail.append((t, c)); readers[t] = 0
+        return t
+
+    def use(*ts):
+        for t in ts: readers[t] += 1
+
+    for _ in range(n_ops):
+        kind = rng.choice(["conv1", "conv1", "conv3", "conv3", "dw", "add", "cat", "ew"])
+        src, c = avail[int(rng.integers(0, len(avail)))]
+        if kind in ("conv1", "conv3"):
+            k = 1 if kind == "conv1" else 3
+            co = int(rng.choice([16, 32, 48]))
+            w = m.add(T(f"w{len(m.tensors)}", (co, k, k, c), "u8", data=_q(rng, (co, k, k, c), 96, 160), scale=0.004, zp=128))
+            b = m.add(T(f"b{len(m.tensors)}", (co,), "i32", data=rng.integers(-300, 300, co), scale=0.0002, zp=0))
+            y = new("c", co)
+            m.ops.append(Op("CONV_2D", [src, w, b], [y], padding=0, stride_w=1, stride_h=1, act=int(rng.choice([0, 1, 3]))))
+            use(src)
+        elif kind == "dw":
+            w = m.add(T(f"dw{len(m.tensors)}", (1, 3, 3, c), "u8", data=_q(rng, (1, 3, 3, c), 64, 192), scale=0.01, zp=128))
+            b = m.add(T(f"db{len(m.tensors)}", (c,), "i32", data=rng.integers(-300, 300, c), scale=0.0005, zp=0))
+            y = new("d", c)
+            m.ops.append(Op("DEPTHWISE_CONV_2D", [src, w, b], [y], padding=0, stride_w=1, stride_h=1, act=3, depth_multiplier=1))
+            use(src)
+        elif kind == "add":
+            same = [t for t, cc in avail if cc == c and t != src]
+            if not same: continue
+            other = same[int(rng.integers(0, len(same)))]
+            y = new("a", c)
+            m.ops.append(Op("ADD", [src, other], [y], act=int(rng.choice([0, 1]))))
+            use(src, other)
+        elif kind == "cat":
+            parts = list(dict.fromkeys([src] + [avail[int(rng.integers(0, len(avail)))][0] for _ in range(int(rng.integers(1, 3)))]))
+            if len(parts) < 2: continue
+            ctot = sum(m.tensors[t].shape[3] for t in parts)
+            if rng.random() < 0.5:   # the output takes its first part's quantisation (that part can then be written in place)
+                y = new("k", ctot, scale=m.tensors[parts[0]].scale, z=m.tensors[parts[0]].zp)
+            else:
+                y = new("k", ctot)
+            m.ops.append(Op("CONCATENATION", list(parts), [y], axis=3))
+            use(*parts)
+        else:
+            code = str(rng.choice(["RELU", "QUANTIZE", "TANH"]))
+            if code == "TANH":
+                y = new("t", c, scale=1 / 128, z=128)
+            else:
+                y = new("e", c)
+            m.ops.append(Op(code, [src], [y]))
+            use(src)
+    leaves = [t for t, _ in avail if readers[t] == 0 and t != x]
+    inner = [t for t, _ in avail if readers[t] > 0 and t != x]
+    extra = [inner[int(i)] for i in rng.integers(0, len(inner), min(3, len(inner)))] if inner else []
+    m.inputs = [x]
+    m.outputs = list(dict.fromkeys(leaves + extra))
+    return m
