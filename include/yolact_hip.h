@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define YH_ABI_VERSION 3
+#define YH_ABI_VERSION 4
 
 enum {
     YH_OK = 0,
@@ -78,8 +78,6 @@ typedef struct yh_tuning {
     int32_t t64;             /* 64x64 tiles for latency-bound launches: 0 off, 1 never split K, 2 split K (2) */
     int32_t t64_maxb;        /* ... when at most this many 128x128 tiles (256) */
     int32_t t64_minsteps;    /* ... split K from this many K-steps (24) */
-    int32_t t64_s4;          /* ring of four for the 64x64 tile (0) */
-    int32_t s4;              /* ring of four for the latency-bound 128x128 tile (0) */
     int32_t stemfuse;        /* fused stem + max pool (1); creation time only */
     int32_t prefuse;         /* preprocessing inside the stem's patch loader (1); creation time only */
     int32_t headmerge;       /* the shared head as one multi-level launch per conv (1); creation time only */
@@ -90,11 +88,12 @@ typedef struct yh_tuning {
                               * descriptors: the loads issue, nothing moves), bit 2 issues no loader instruction at all */
     int32_t op_tile;         /* single-op entry points: force this ConvTile id (-1: the engine's choice) */
     int32_t op_kslices;      /* single-op entry points: force a split-K with this many slices */
-    int32_t tfl_dot;         /* TFLite path, CONV_2D: 0 one lane per output element, 1 the v_dot4 kernel (Ci % 4 == 0), 2 also the int8 MFMA
-                              * kernel on LDS tiles where Ci % 64 == 0, 3 (default) the int8 MFMA kernel fed from registers (one wave per
-                              * 32 x 32 tile, no LDS, eight k-steps of loads in flight) where Ci % 16 == 0; all four give the same bytes */
-    int32_t tfl_graph;       /* TFLite path: 0 eager launches (default, and the faster form: 1.10 vs 1.22 ms), 1 hipGraph replay
-                              * of the plan (captured with a second, one-node branch: DESIGN.md §8 on single-branch graphs) */
+    int32_t tfl_dot;         /* TFLite path (yh_tfl handles only), CONV_2D: 0 one lane per output element, 1 the v_dot4 kernel (Ci % 4 == 0),
+                              * 2 also the int8 MFMA kernel on 64 x 64 LDS tiles where Ci % 64 == 0, 3 (default) the int8 MFMA kernel fed from
+                              * registers - one wave per 16 x 16 tile of v_mfma_i32_16x16x64_i8, no LDS, a ring of 1-18 k-steps of loads in
+                              * flight - where Ci % 4 == 0 (large long-K layers keep the LDS tiles); all four give the same bytes */
+    int32_t tfl_graph;       /* TFLite path: 0 eager launches (default, and the faster form: 0.33 vs 0.37 ms per invoke of the 136-op
+                              * model), 1 hipGraph replay of the plan (captured with a second, one-node branch: DESIGN.md §8) */
     int32_t tailfork;        /* the detection tail's K1-K3 on a second stream underneath the protonet (1); 0 keeps them on
                               * the main stream */
     int32_t dsfuse;          /* a stage's projection shortcut evaluated inside the block's last 1x1 conv (two-source K, 1);
@@ -108,39 +107,18 @@ typedef struct yh_tuning {
     int32_t k1_min3;         /* ... and (10 = 2.5 per CU) for the 3x3 layers with few big tiles and the head's remainder */
     int32_t chain;           /* identity bottleneck blocks of layers 1-2 as ONE launch each: 3x3 conv + 1x1 expand conv with the residual
                               * add + the next block's 1x1 reduce conv (csrc/bneck.hip; bit-identical to the separate launches). Bit 0
-                              * on, bit 1 128-pixel tiles for 64 planes, bit 2 a persistent grid (two workgroups per CU) instead
-                              * of one workgroup per tile, bit 3 (with bit 2) a phase stagger between co-resident workgroups, bit 4
-                              * also fuse launches that only fill 64-pixel tiles (small batches: 3 % faster at batch 1-8), bits 8..
-                              * the stagger in units of 4096 clocks. Default 17 (bits 0 and 4). Bits 1-3 are measured A/B forms, all
-                              * slower than the default; bit 5 layer 1 only, bit 6 without the fused form of layer 1's FIRST block
-                              * (projection shortcut), bit 7 without layer 3's expand + next-reduce launch (bneck_xn_f16: used where
-                              * its 64-pixel tiles fill more than half a round of workgroups and at most one) */
-    int32_t xn_tm;           /* layer 3's expand + next-reduce launch, pixel tile: -1 (default) 64-pixel tiles for about one round of
-                              * workgroups (bneck_xn_f16), else separate launches; 64 / 128: that form wherever the launch is eligible
-                              * (128: bneck_xn128_f16, bit-identical, measured no faster than the separate launches at batch 64) */
-    int32_t xn_pipe;         /* layer 3's expand + next-reduce launch: 1 the pipelined kernel (bneck_xn2_f16: one barrier per chunk, GEMM 2 of
-                              * chunk t beside GEMM 3 of chunk t - 1, W_a' fragments in registers), 0 the two-phase kernels; same bytes */
-    int32_t fp8_s3;          /* fp8 precision: launches of about one 128 x 128 tile per CU on a ring of three LDS stages (two tiles in flight)
-                              * instead of 64 x 64 tiles (YOLACT-700 R101 at 8 frames: layer 3); same bytes */
+                              * on; bit 4 also fuse launches that only fill 64-pixel tiles (small batches: 3 % faster at batch 1-8).
+                              * Default 17 (bits 0 and 4). Test switches: bit 1 layer 3's expand + next-reduce launch (bneck_xn_f16)
+                              * wherever it is eligible instead of only inside its window (64-pixel tiles filling more than half a round
+                              * of workgroups and at most one), bit 5 layer 1 only, bit 6 without the fused form of layer 1's FIRST block
+                              * (projection shortcut), bit 7 without layer 3's launch. Bits 2-3 (round 3's persistent grid and phase
+                              * stagger) are retired and ignored */
     int32_t tfl_fuse;        /* TFLite path: 1 (default) element-wise operators (QUANTIZE / RELU / RELU6 / TANH / ADD), PAD and contiguous
                               * CONCATENATION parts folded into the launch of the convolution / resize that produces their operand -
                               * same bytes, fewer launches; 0: one launch per operator, every tensor materialised (the checker) */
-    int32_t tfl_streams;     /* TFLite path: streams the plan's independent launches are spread over inside an invoke (forked from and joined
-                              * into the handle's stream; at most 8); 1 (default): everything on the handle's stream. Same bytes; measured neutral
-                              * on the 136-op model (its backbone is a chain), kept as a knob. A captured plan (tfl_graph = 1) keeps one lane */
-    int32_t splitk_inl;      /* split-K convolutions: 1 the workgroup whose K slice arrives last sums the tile's slabs and runs the epilogue
-                              * inside the launch (one arrival counter per tile, nobody waits); 0 (default): splitk_reduce_f16 does, as a
-                              * second launch. Same bytes (the slabs are summed in slice order in both forms). Measured: 16 launches fewer
-                              * at batch 1 and the step SLOWER (0.718 -> 0.896 ms; batch 4: 1.269 -> 1.390) - one workgroup reads a tile's
-                              * 8-16 slabs alone where the reduce launch spreads them over the chip */
-    int32_t direct;          /* > 0: f16 1x1 / 3x3 convolutions of 24-36 k-steps and at most this many workgroups of 32 x 32 (layer 4's 1x1
-                              * reductions, lat5, P5-P7 at batch 1 with 192) run on conv_direct_f16 - tiles fed from registers, K split over
-                              * the four waves of a workgroup, no slab and no reduce launch. Default 0 (off): measured neutral per step
-                              * (0.713 vs 0.711 ms at batch 1) and slower on every larger launch (engine.hip, fill_conv_params). Same
-                              * convolution, another summation order (f32): within f16 rounding of the tiled kernels, not bit for bit */
     int32_t tfl_group;       /* TFLite path: 1 (default) independent register-fed convolutions of one kernel form at one depth of the plan's
                               * graph as ONE launch (the prediction head's convolutions over the pyramid levels: 23 launches become 3), the
-                              * plan in depth order; 0: one launch per convolution in file order. Same bytes. Only with tfl_streams = 1 */
+                              * plan in depth order; 0: one launch per convolution in file order. Same bytes */
 } yh_tuning;
 
 typedef struct yh_config {
@@ -198,7 +176,8 @@ void yh_default_config(yh_config* cfg);
  * call); YH_ESTATE if a creation-time field (bigk, stemfuse, prefuse, headmerge, upfuse, dsfuse, protofuse) differs from
  * the handle's. */
 int yh_set_tuning(yh_engine* h, const yh_tuning* tune);
-/* The handle's tuning with every default resolved (plan_cus = the CU count the plans really use, ...). */
+/* The handle's tuning with every default resolved (plan_cus = the CU count the plans really use, ...). The tfl_* fields belong to
+ * yh_tfl handles (yh_tfl_create_tuned) and stay -1: an engine handle does not carry them. */
 int yh_get_tuning(const yh_engine* h, yh_tuning* out);
 
 /* FlatBufferModel::build_from_file + InterpreterBuilder::new/build + EdgeTpuContext::open_device +
@@ -293,6 +272,12 @@ int yh_group_fp8_calibrate(yh_group* g);
 int yh_group_evaluate(yh_group* g, const uint8_t* frames_host, int32_t n_frames, int32_t with_tail);
 /* The same with frames resident on each member's own device: frames_dev[i] holds counts[i] frames (0: the member sits out). */
 int yh_group_evaluate_device(yh_group* g, const uint8_t* const* frames_dev, const int32_t* counts, int32_t with_tail);
+/* Captures, on the CALLING thread and one member after the other, the step every member would run for a call with n_frames frames
+ * (both input buffers of each member's block size): what the first yh_group_evaluate* of that size would otherwise do before it starts
+ * its workers. A host calls it for the frame counts it will use at start-up, so that no capture falls into its frame loop (the
+ * reference allocates everything in Yolact::init, src/yolact.rs:28-35). Needs the weights (fp8 precision: and the scales). The group's
+ * worker threads never capture and never allocate: DESIGN.md section 7. */
+int yh_group_prepare(yh_group* g, int32_t n_frames, int32_t with_tail);
 int yh_group_sync(yh_group* g);
 /* Results by GLOBAL frame index of the last yh_group_evaluate* (waits for that member's step): as yh_read_detections. */
 int yh_group_read_detections(yh_group* g, int32_t frame, int32_t* count, yh_detection* dets, int32_t dets_capacity, uint8_t* masks, size_t masks_capacity);
@@ -312,6 +297,11 @@ int yh_set_input_u8_device(yh_engine* h, const uint8_t* rgb_dev, int32_t n_frame
 /* interpreter.invoke() (src/yolact.rs:163): the network forward for the frames last set.
  * Asynchronous on the handle's stream; yh_sync or any output read waits for it. */
 int yh_invoke(yh_engine* h);
+/* allocate_tensors() at its proper time (src/yolact.rs:35): captures the step for n_frames frames (with_tail: yh_evaluate's, else
+ * yh_invoke's) for both input buffers NOW, on the calling thread, instead of at the first yh_invoke / yh_evaluate of that batch size.
+ * A no-op for use_graph = 0. A host that drives several handles from several threads calls this for each handle, serially, before
+ * those threads start (a capture is once-only work deep in the HIP runtime; the library never does it on a group's worker thread). */
+int yh_prepare(yh_engine* h, int32_t n_frames, int32_t with_tail);
 int yh_sync(yh_engine* h);
 /* interpreter.outputs().len() / tensor_info(output) (src/yolact.rs:166,170). Output order:
  *   0 loc    [n,P,4]  f16   box regressions
@@ -389,7 +379,7 @@ typedef struct yh_tfl yh_tfl;
 int yh_tfl_validate(const void* model_bytes, size_t nbytes, int32_t* n_tensors, int32_t* n_ops, char* err, size_t err_cap);
 /* FlatBufferModel::build_from_file + InterpreterBuilder + allocate_tensors (src/yolact.rs:18-35). */
 int yh_tfl_create(const void* model_bytes, size_t nbytes, int32_t device, yh_tfl** out);
-/* Same with the TFLite fields of a tuning struct (tfl_dot, tfl_graph; tune may be NULL). */
+/* Same with the TFLite fields of a tuning struct (tfl_dot, tfl_graph, tfl_fuse, tfl_group; tune may be NULL). */
 int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, const yh_tuning* tune, yh_tfl** out);
 void yh_tfl_destroy(yh_tfl* h);
 const char* yh_tfl_last_error(const yh_tfl* h);
@@ -457,6 +447,10 @@ int yh_debug_last_conv_launches(const yh_engine* h);
  * with [base, end) and where those sit inside their 2 MiB page; the nodes of the step for the current batch size as the
  * handle's tuning captures it (kernel symbol, grid, block, the pointers of its launch argument), sorted. */
 int yh_debug_alloc_map(yh_engine* h, char* out, size_t cap);
+/* Process-wide counters of the setup discipline: out[0] once-only setup sections entered (graph captures), out[1]
+ * jobs run by group worker threads, out[2] times one of the former overlapped one of the latter anywhere in the process (must stay 0),
+ * out[3] sections / jobs in flight right now. */
+int yh_debug_setup_audit(int64_t out[4]);
 int yh_debug_graph_nodes(yh_engine* h, int32_t with_tail, char* out, size_t cap);
 
 /* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */

@@ -1,7 +1,12 @@
+import faulthandler
 import os
 import sys
 
 import pytest
+
+# A crash inside the HIP runtime or the library (SIGSEGV / SIGABRT / SIGBUS) must leave the Python stack of every thread in the log:
+# round 4 lost a host segfault in a full GPU run because nothing had been armed to say where it happened.
+faulthandler.enable(all_threads=True)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tiny-object-detection_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):

@@ -30,7 +30,7 @@ def test_version_and_defaults(built):
     assert b"gfx950" in L.yh_version()
     cfg = capi.Config()
     L.yh_default_config(cfg)
-    assert (cfg.abi_version, cfg.backbone, cfg.input_size, cfg.num_classes, cfg.top_k, cfg.max_dets) == (3, 50, 550, 81, 200, 100)
+    assert (cfg.abi_version, cfg.backbone, cfg.input_size, cfg.num_classes, cfg.top_k, cfg.max_dets) == (4, 50, 550, 81, 200, 100)
     assert abs(cfg.conf_thresh - 0.05) < 1e-7 and cfg.nms_thresh == 0.5
     assert cfg.precision == capi.PRECISION_F16 and all(v == -1 for v in cfg.tune.as_dict().values())
 

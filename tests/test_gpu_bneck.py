@@ -23,9 +23,7 @@ def _pair(ya, n, **tune):
 DUAL = "bneck_chain_f16<64,128,next,dual"
 
 
-XN = "bneck_xn_f16"
-XN2_64, XN2_128 = "bneck_xn2_f16<64", "bneck_xn2_f16<128"   # round 4: the pipelined form (tune.xn_pipe = 1): one barrier per chunk, W_a' fragments in registers
-XN128 = "bneck_xn128_f16"   # round 4: the same launch on 128-pixel tiles (tune.xn_tm = 128; not in the default plan)
+XN = "bneck_xn_f16"   # (round 4's 128-pixel and pipelined forms of this launch are retired: tools/study/retired_r05_forms.patch)
 
 
 @pytest.mark.parametrize("n,tune,want,chains,nexts,xn", [
@@ -34,17 +32,8 @@ XN128 = "bneck_xn128_f16"   # round 4: the same launch on 128-pixel tiles (tune.
     (8, {"chain": 17 + 128}, {"bneck_chain_f16<64,64", "bneck_chain_f16<128,64", DUAL}, 6, 4, 0),        # ... without them (bit 7)
     (8, {"plan_cus": 64}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,64", DUAL}, 6, 4, 0),          # planned for a 64-CU chip: 595 big tiles in layer 1 (>= 8 per CU), 298 in layer 2
     (8, {"plan_cus": 32}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128", DUAL}, 6, 4, 0),         # planned for a 32-CU chip: both big tiles + the first-block form (the default plan of a batch-64 step)
-    (8, {"plan_cus": 32, "xn_tm": 128}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128", DUAL, XN128}, 6, 4, 4),   # ... with layer 3 on 128-pixel tiles (77 tiles of which the last holds 72 rows)
     (8, {"plan_cus": 32, "chain": 65}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 5, 3, 0),  # without the first-block form (bit 6)
-    (8, {"plan_cus": 32, "chain": 13}, {"bneck_chain_f16<64,256", "bneck_chain_f16<128,128"}, 6, 4, 0),  # persistent grid + phase stagger (A/B forms)
-    (8, {"plan_cus": 32, "chain": 3}, {"bneck_chain_f16<64,128"}, 6, 4, 0),                              # the 128-pixel form of the 64-plane tile
-    (3, {"xn_tm": 128}, {XN128, DUAL}, 6, 4, 4),                                                          # the 128-pixel form forced on a full chip: 3 675 pixels = 28 tiles + 91 rows (a last tile whose second row pass is partly past M)
-    (1, {"xn_tm": 128}, {XN128}, 6, 4, 4),                                                                # ... 1 225 pixels: a last tile of 73 rows
-    (2, {"xn_tm": 64}, {XN}, 6, 4, 4),                                                                    # the 64-pixel form forced outside its window
-    (8, {"xn_pipe": 1}, {XN2_64, DUAL}, 6, 4, 4),                                                         # the pipelined kernel in the 64-pixel form's window (154 tiles of which the last holds 8 rows)
-    (8, {"plan_cus": 32, "xn_tm": 128, "xn_pipe": 1}, {XN2_128, "bneck_chain_f16<128,128"}, 6, 4, 4),    # ... on 128-pixel tiles
-    (3, {"xn_tm": 128, "xn_pipe": 1}, {XN2_128}, 6, 4, 4),                                                # ... 28 tiles + 91 rows
-    (1, {"xn_tm": 64, "xn_pipe": 1}, {XN2_64}, 6, 4, 4),                                                  # ... 19 tiles + 9 rows
+    (2, {"chain": 17 + 2}, {XN}, 6, 4, 4),                                                               # the 64-pixel form forced outside its window (bit 1), 38 tiles + 18 rows
 ])
 def test_chain_equals_separate_launches_bit_for_bit(built, n, tune, want, chains, nexts, xn):
     import yolact_amd as ya
@@ -92,20 +81,18 @@ def test_chain_layers_against_the_oracle(built, oracle):
         a, b = eng.tensor_frame(name, 1), net.get(name)[0]
         assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()))
     eng.close()
-    # layer 3's expand + next-reduce launch in both tile sizes: its two outputs per block against the oracle's forward
-    for tm, pipe, sym in ((128, 0, XN128), (64, 0, XN), (128, 1, XN2_128 + ">"), (64, 1, XN2_64 + ">")):
-        eng = ya.Engine(input_size=S, max_batch=2, use_graph=True, tune=dict(xn_tm=tm, xn_pipe=pipe))
-        eng.load_weights(blob)
-        eng.set_input(frames); eng.evaluate()
-        assert sum(p["name"].startswith(sym + ":") for p in eng.profile(with_tail=False, reps=1)) == 4
-        for name, tol in (("l3b1", 1.5e-2), ("l3b2_a", 1.5e-2), ("l3b4", 1.5e-2), ("l3b5_a", 1.5e-2), ("c4", 1.5e-2)):
-            a, b = eng.tensor_frame(name, 1), net.get(name)[0]
-            assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (tm, name, float(np.abs(a - b).max()))
-        eng.close()
+    # layer 3's expand + next-reduce launch: its two outputs per block against the oracle's forward
+    eng = ya.Engine(input_size=S, max_batch=2, use_graph=True, tune=dict(chain=17 + 2))
+    eng.load_weights(blob)
+    eng.set_input(frames); eng.evaluate()
+    assert sum(p["name"].startswith(XN + ":") for p in eng.profile(with_tail=False, reps=1)) == 4
+    for name, tol in (("l3b1", 1.5e-2), ("l3b2_a", 1.5e-2), ("l3b4", 1.5e-2), ("l3b5_a", 1.5e-2), ("c4", 1.5e-2)):
+        a, b = eng.tensor_frame(name, 1), net.get(name)[0]
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (name, float(np.abs(a - b).max()))
+    eng.close()
 
 
-@pytest.mark.parametrize("xn_tm,pipe,sym", [(-1, 0, XN), (128, 0, XN128), (-1, 1, XN2_64 + ">"), (128, 1, XN2_128 + ">")])
-def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, pipe, sym):
+def test_layer3_launch_in_fp8_precision_equals_separate_launches(built):
     """configs[4]'s own share (YOLACT-700 R101, fp8 precision, 8 frames per GPU) is where layer 3's expand + next-reduce launch runs
     (242 tiles on 256 CUs), and there its second output feeds an fp8 convolution: a' is written as E4M3 codes by the fused launch.
     Same bytes as the separate launches on every head output and detection."""
@@ -113,7 +100,7 @@ def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, p
     n, s = 8, 700
     frames = np.random.default_rng(21).integers(0, 256, (n, s, s, 3), dtype=np.uint8)
     engs, blob = [], None
-    for tune in ({"xn_tm": xn_tm, "xn_pipe": pipe}, {"chain": 17 + 128}):
+    for tune in ({}, {"chain": 17 + 128}):
         e = ya.Engine(input_size=s, backbone=101, max_batch=n, use_graph=True, precision=ya.PRECISION_FP8, tune=tune or None)
         if blob is None:
             blob = e.generate_weights(seed=1)
@@ -124,7 +111,7 @@ def test_layer3_launch_in_fp8_precision_equals_separate_launches(built, xn_tm, p
         engs.append(e)
     f, u = engs
     names = [p["name"] for p in f.profile(with_tail=True, reps=1)]
-    assert sum(nm.startswith(sym + ":") for nm in names) == 21, names          # l3b1 ... l3b21 (+ the next block's reduce conv each)
+    assert sum(nm.startswith(XN + ":") for nm in names) == 21, names          # l3b1 ... l3b21 (+ the next block's reduce conv each)
     assert not any(nm.startswith("bneck_xn") for nm in (p["name"] for p in u.profile(with_tail=True, reps=1)))
     for i in range(4):
         assert np.array_equal(f.output(i), u.output(i)), i

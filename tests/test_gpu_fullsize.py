@@ -173,34 +173,6 @@ def test_second_stream_changes_no_bit_over_many_steps(built):
         two.close(); one.close()
 
 
-def test_in_launch_split_k_reduction_changes_no_bit(built):
-    """yh_tuning.splitk_inl = 1 (the workgroup whose K slice arrives last sums the tile's slabs inside the launch: one arrival
-    counter per tile, reset by the reducer, counters shared by the launches of a stream) against the default (splitk_reduce_f16
-    as a launch of its own): batch 1 and 2 at full size, 8 graph-replayed steps on changing frames, every output and detection
-    bitwise equal - a stale slab, a counter left non-zero or a reducer that ran early would show here."""
-    import yolact_amd as ya
-    rng = np.random.default_rng(33)
-    for n in (1, 2):
-        a = ya.Engine(input_size=S, max_batch=n, use_graph=True)
-        b = ya.Engine(input_size=S, max_batch=n, use_graph=True, tune=dict(splitk_inl=1))
-        blob = a.generate_weights(seed=1)
-        a.load_weights(blob); b.load_weights(blob)
-        for step in range(8):
-            frames = rng.integers(0, 256, (n, S, S, 3), dtype=np.uint8)
-            outs = []
-            for e in (a, b):
-                e.set_input(frames)
-                e.evaluate()
-                outs.append(([e.output(i) for i in range(4)], [e.detections(f) for f in range(n)]))
-            for x, y in zip(outs[0][0], outs[1][0]):
-                assert np.array_equal(x, y), (n, step)
-            for (da, ma), (db, mb) in zip(outs[0][1], outs[1][1]):
-                assert da == db and np.array_equal(ma, mb), (n, step)
-        la, lb = len(a.profile(reps=1)), len(b.profile(reps=1))
-        assert lb <= la - 10, (la, lb)   # (batch 1: 16 reduce launches fewer)
-        a.close(); b.close()
-
-
 # ---- configs[2]: batch 64, hipGraph steady state (BASELINE.json; tiles -> batch entries, src/yolact.rs:216-217) ----
 LAYERS_550 = (("pool", 2e-3), ("c2", 6e-3), ("c3", 1e-2), ("c4", 1.5e-2), ("c5", 2e-2), ("lat5", 2e-2), ("lat4", 2e-2), ("lat3", 2e-2),
               ("p3", 2e-2), ("p4", 2e-2), ("p5", 2e-2), ("p6", 2.5e-2), ("p7", 2.5e-2), ("proto0", 2.5e-2), ("proto2", 2.5e-2),

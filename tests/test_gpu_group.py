@@ -20,7 +20,7 @@ TH = 0.005
 
 def _single(ya, blob, S, max_batch, blocks, **kw):
     """Reference results: ONE engine, one block of frames at a time, serially."""
-    e = ya.Engine(input_size=S, max_batch=max_batch, use_graph=True, conf_thresh=TH, **kw)
+    e = ya.Engine(input_size=S, max_batch=max_batch, conf_thresh=TH, **dict(dict(use_graph=True), **kw))
     e.load_weights(blob)
     out = []
     for fr in blocks:
@@ -107,6 +107,51 @@ def test_group_of_two_members_on_one_device_equals_single_engine(built, S, per):
     for f in range(2 * per):
         assert _same(g.detections(f), want[f]), f
     g.close()
+
+
+def test_group_prepares_on_the_callers_thread_and_workers_never_capture(built):
+    """The setup discipline of DESIGN.md section 7: every graph capture of a group happens on the CALLING thread, one member after the
+    other, while no worker thread is inside a HIP call. Two block sizes alternate (5 frames -> blocks 3 + 2, 6 -> 3 + 3, 2 -> 1 + 1:
+    member 1 meets three shapes, two of them only after the group has been running), a third appears late, and the process-wide
+    audit counters must show captures and worker jobs but NOT ONE overlap of the two; results stay bit-equal to a single engine.
+    (Round 4: a member capturing beside a neighbour's once-only allocation, both on worker threads, ended a full test run with a
+    host segfault. The group's first steps on threads - capture + first host input - are exactly what this test takes, once.)"""
+    import yolact_amd as ya
+    S, per = 256, 3
+    a0 = ya.setup_audit()
+    g = ya.Group([0, 0], input_size=S, max_batch=per, conf_thresh=TH)
+    blob = g.members[0].generate_weights(seed=1)
+    g.load_weights(blob)
+    g.prepare(5)                                           # explicit: blocks of 3 and 2, both input buffers each = 4 captures
+    a1 = ya.setup_audit()
+    assert a1["setups"] - a0["setups"] == 4 and a1["worker_jobs"] == a0["worker_jobs"], (a0, a1)
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (6, S, S, 3), dtype=np.uint8)
+    for it, n in enumerate((5, 6, 5, 6, 5, 2, 6, 5)):      # 6 -> member 1 needs a block of 3 (late capture), 2 -> both need blocks of 1
+        g.evaluate(frames[:n])
+        want = _single(ya, blob, S, per, [frames[:(n + 1) // 2], frames[(n + 1) // 2:n]])
+        for f in range(n):
+            assert _same(g.detections(f), want[f]), (it, n, f)
+    a2 = ya.setup_audit()
+    # captures after prepare: member 1 at 3 frames (2) + both members at 1 frame (4); _single's engines capture too (on this thread)
+    assert a2["setups"] - a1["setups"] >= 6 and a2["worker_jobs"] - a1["worker_jobs"] == 16, (a1, a2)
+    assert a2["overlaps"] == a0["overlaps"] == 0 and a2["in_flight"] == 0, (a0, a2)
+    # a member handed to a worker with an unprepared shape refuses instead of capturing there: forced through the handle's own
+    # entry points this cannot be reached from outside, so the rule is checked where it lives - eager members have nothing to
+    # capture and take their first step on the caller's thread
+    ge = ya.Group([0, 0], input_size=S, max_batch=per, conf_thresh=TH, use_graph=False)
+    ge.load_weights(blob)
+    b0 = ya.setup_audit()
+    ge.evaluate(frames[:5])                                # first step of both members: inline, no worker job
+    b1 = ya.setup_audit()
+    assert b1["worker_jobs"] == b0["worker_jobs"] and b1["setups"] == b0["setups"], (b0, b1)
+    ge.evaluate(frames[:5])                                # second: on the workers
+    b2 = ya.setup_audit()
+    assert b2["worker_jobs"] - b1["worker_jobs"] == 2 and b2["overlaps"] == 0, (b1, b2)
+    want = _single(ya, blob, S, per, [frames[:3], frames[3:5]], use_graph=False)
+    for f in range(5):
+        assert _same(ge.detections(f), want[f]), f
+    g.close(); ge.close()
 
 
 def test_group_evaluate_device_with_resident_frames(built):

@@ -190,7 +190,7 @@ def _forced(eng, tune, fn):
         eng.reset_tuning(*tune)
 
 
-@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _TILES] + [("128x128_S3", 3), ("64x64_S3", 4), ("128x128_S3", -3), ("64x64_S3", -4)])
+@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _TILES] + [("128x128_S3", 3), ("64x64_S3", 4)])
 @pytest.mark.parametrize("k", [3, 1])
 def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
     """The shared head's multi-level form (one launch over pyramid levels laid end to end) on every tile
@@ -204,7 +204,7 @@ def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
     wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
     b = rng.integers(-4, 5, cout).astype(np.float32)
     env = {"op_tile": _TILES[tile]}
-    if kslices: env.update(op_kslices=abs(kslices), splitk_inl=int(kslices < 0))   # (negative: the slabs are summed inside the launch)
+    if kslices: env.update(op_kslices=kslices)
     y = _forced(eng, env, lambda: eng.op_conv2d_levels(x, sizes, wt, b, act=1))
     off = 0
     for s_ in sizes:
@@ -214,7 +214,7 @@ def test_conv_multilevel_exact_on_integers(eng, oracle, tile, kslices, k):
         off += s_ * s_
 
 
-@pytest.mark.parametrize("tile,kslices", [("128x128_S3", 0), ("64x64_S3", 0), ("128x128_S3", 2), ("64x64_S3", 5), ("128x128_S3", -2), ("64x64_S3", -5), ("128x128_M16", 0), ("128x128_S3_M16", 0), ("DIRECT32", 0)])
+@pytest.mark.parametrize("tile,kslices", [("128x128_S3", 0), ("64x64_S3", 0), ("128x128_S3", 2), ("64x64_S3", 5), ("128x128_M16", 0), ("128x128_S3_M16", 0)])
 def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     """The latency-bound tile variants the engine picks at small batch (3-stage 128x128 and 64x64 rings,
     their split-K forms, the 16x16x32 tail tiles), forced through the op entry: ragged M, residual, ReLU."""
@@ -223,8 +223,8 @@ def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
     wt = rng.integers(-2, 3, (192, 3, 3, 128)).astype(np.float32)
     b = rng.integers(-4, 5, 192).astype(np.float32)
     r = rng.integers(-5, 6, (2, 13, 11, 192)).astype(np.float32)
-    env = {"op_tile": 26 if tile == "DIRECT32" else _TILES[tile]}   # (26: conv_direct_f16, csrc/conv_direct.hip)
-    if kslices: env.update(op_kslices=abs(kslices), splitk_inl=int(kslices < 0))   # (negative: the slabs are summed inside the launch)
+    env = {"op_tile": _TILES[tile]}
+    if kslices: env.update(op_kslices=kslices)
     y = _forced(eng, env, lambda: eng.op_conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1))
     assert np.array_equal(y, oracle.conv2d(f16(x), f16(wt), b, 1, 1, f16(r), 1, f16=True))
 
@@ -232,7 +232,7 @@ def test_conv_small_tile_variants_exact_on_integers(eng, oracle, tile, kslices):
 _DUAL_TILES = {"128x128": 0, "128x128_K1": 21, "128x128_S3": 7, "64x64_S3": 16, "128x128_M16": 12, "128x128_S3_M16": 13, "256x256_M16": 8}
 
 
-@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _DUAL_TILES] + [("128x128_S3", 2), ("128x128_S3", 3), ("64x64_S3", 2), ("64x64_S3", 5), ("128x128_S3", -3), ("64x64_S3", -5)])
+@pytest.mark.parametrize("tile,kslices", [(t, 0) for t in _DUAL_TILES] + [("128x128_S3", 2), ("128x128_S3", 3), ("64x64_S3", 2), ("64x64_S3", 5)])
 @pytest.mark.parametrize("stride2,c1,c2", [(1, 64, 64), (2, 128, 256), (2, 64, 192)])
 def test_dual_source_conv_exact_on_integers(eng, oracle, tile, kslices, stride2, c1, c2):
     """The two-source 1x1 form (a bottleneck block's last conv + its projection shortcut as one accumulation over
@@ -247,7 +247,7 @@ def test_dual_source_conv_exact_on_integers(eng, oracle, tile, kslices, stride2,
     wt = rng.integers(-2, 3, (cout, c1 + c2)).astype(np.float32)
     b = rng.integers(-4, 5, cout).astype(np.float32)
     env = {"op_tile": _DUAL_TILES[tile]}
-    if kslices: env.update(op_kslices=abs(kslices), splitk_inl=int(kslices < 0))   # (negative: the slabs are summed inside the launch)
+    if kslices: env.update(op_kslices=kslices)
     y = _forced(eng, env, lambda: eng.op_conv2d_dual(x1, x2, stride2, wt, b, act=1))
     cat = np.concatenate([x1, x2[:, ::stride2, ::stride2][:, :ho, :wo]], axis=-1)
     yo = oracle.conv2d(f16(cat), f16(wt.reshape(cout, 1, 1, c1 + c2)), b, 1, 0, None, 1, f16=True)

@@ -227,26 +227,6 @@ def test_graph_replay_equals_eager_over_200_replays(built):
     eager.close(); graph.close()
 
 
-@pytest.mark.parametrize("fuse", [0, 1])
-def test_plan_spread_over_four_streams_equals_one_stream(built, fuse):
-    """yh_tuning.tfl_streams = 4 (independent launches of the plan side by side on four streams, ordered by events:
-    schedule_plan in tflite_exec.hip) against the single-stream plan: 40 invokes on changing inputs, every output equal bit
-    for bit - a missing dependency edge between lanes would show up as a stale read here."""
-    import yolact_amd as ya
-    rng = np.random.default_rng(11)
-    buf = bytes(B.serialize(M.mobilenetv2_yolact(rng)))
-    one, four = ya.TfliteEngine(buf, tune=dict(tfl_fuse=fuse, tfl_streams=1)), ya.TfliteEngine(buf, tune=dict(tfl_fuse=fuse, tfl_streams=4))
-    for it in range(40):
-        x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
-        for e in (one, four):
-            e.set_input(x)
-            e.invoke()
-        if it % 4 == 0 or it == 39:
-            for k in range(5):
-                assert np.array_equal(one.output(k), four.output(k)), (it, k)
-    one.close(); four.close()
-
-
 def test_classify_through_a_tflite_model(built, oracle, golden_dir):
     """Yolact::classify (yolact.rs:192-234) with a .tflite in the middle: pre-processing, two
     invokes, output-4 dequantisation (yolact.rs:177), postprocess, stitch, resize back."""

@@ -99,14 +99,8 @@ __global__ __launch_bounds__(256, 2) void bneck_chain_f16(const BneckParams p) {
     char* const wt3 = lds + A_BYTES + ST_BYTES;
     char* const x2t = lds + A_BYTES + ST_BYTES + WT3_BYTES;
 
-    // Persistent grid: workgroup w walks tiles w, w + grid, ... The workgroups that share a CU run the same program: started
-    // together they stay in lockstep (both in the MFMA / L2-bound 3x3 phase, then both in the HBM-bound expand phase) and the
-    // kernel takes the SUM of the two phases. The second-dispatched half of the grid therefore starts p.stagger sleep units
-    // (64 clocks each) late - once -, which puts the co-resident workgroups in opposite phases for the rest of the launch
-    // (which workgroups share a CU is the dispatcher's business: a wrong guess costs the delay, never correctness).
+    // (one workgroup per tile; the loop form is kept from the persistent-grid experiment of round 3, which measured slower: DESIGN.md section 4)
     const int nwg = gridDim.x, bid = blockIdx.x;
-    if (p.stagger > 0 && bid >= (nwg >> 1))
-        for (int t = 0; t < p.stagger; t += 127) __builtin_amdgcn_s_sleep(127);
     const int ntiles = (p.M + TM - 1) / TM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -600,485 +594,8 @@ __global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// bneck_xn128_f16 - the same launch on 128-PIXEL tiles, for launches of several rounds of workgroups (YOLACT-550 at batch 64:
-// layer 3 is 78 400 pixels = 613 tiles). The 64-pixel form streams both weight panels (1 MB) through LDS once per 64 pixels
-// and is bound by the L2 -> LDS path (~40 us per round: good where the separate launches are latency bound, 1.2-2 x slower
-// than them once they fill the chip). Twice the pixels per weight byte halves that traffic.
-//
-// What shaped it (round 4, measured): a first version with eight symmetric waves - every wave issuing its share of every
-// stream - was bit-exact and no faster than the two launches (157 vs 162 us): vmcnt completes IN ORDER per wave, so a wave that
-// waits for a weight tile it requested half a step ago also waits for every older request of its own, and the residual rows
-// (HBM, 2-3 us under load) could never be more than one step ahead of their use whatever the ring depth: 6 900 clocks per step
-// for 96 KB. So the streams are split BY WAVE, one in-order queue per latency class:
-//   waves 0-3 (compute)  the residual rows, THREE steps ahead, into a ring of four stages [128 px][64 ch] | GEMM 2: 64 ch x 32 px
-//                        per wave (K = 256 out of b fragments in REGISTERS) + bias + residual, ReLU, f16, in place |M| the y
-//                        chunk's whole-row stores, their half of GEMM 3 |E|
-//   waves 4-7 (loaders)  W_a' tile of THIS step (one stage: it lands under GEMM 2), W_c tile of the next (two stages) |M| their
-//                        half of GEMM 3 |E|
-// LDS: W_c 2 x 32 KB, W_a' 32 KB, stages 4 x 16 KB = 160 KB, one workgroup per CU; biases through the scalar cache (bias_quad).
-// Every step issues the same instructions - requests past the last chunk carry an out-of-range offset (the buffer returns
-// zeros into a free slot, no memory traffic), the y stores are BUFFER stores (rows past M are dropped by the range check, the
-// instruction still counts) - so every counted wait is a constant: compute waves vmcnt(20) at |E| (all but the five youngest
-// groups of four: residual(oc+3), stores(oc), residual(oc+2), stores(oc-1), stores(oc-2) ... = what was issued after
-// residual(oc+1)), loaders vmcnt(8) at |M| and vmcnt(0) at |E|. A stream is waited for by the wave that issued it and read after
-// the barrier behind that wait. Same MFMA products in the same order and the same f32 epilogue operations as the two separate
-// launches: bit-identical.
-__global__ __launch_bounds__(512, 1) void bneck_xn128_f16(const BneckParams p) {
-    constexpr int PL = 256, TM = 128, KT = 4, C4 = 1024, NOC = 16, NST = 4;
-    constexpr int WC_BYTES = KT * 64 * 128, WA_BYTES = PL * 128, ST_BYTES = TM * 128;   // 32 KB, 32 KB, 16 KB
-    constexpr int WA_OFF = 2 * WC_BYTES, ST_OFF = WA_OFF + WA_BYTES;
-    constexpr unsigned OOB = 0xFFFFFF00u;   // past every descriptor's range (the engine keeps them below it)
-    static_assert(ST_OFF + NST * ST_BYTES <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char lds[ST_OFF + NST * ST_BYTES];
-    lds_char* const lds3 = (lds_char*)lds;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wv >= 4;
-    const int wave = wv & 3, lt = tid & 255;
-    const int pc = lt & 7, rb = lt >> 3, lc = pc ^ ((rb >> 1) & 7);     // row-pass role: physical chunk pc of rows rb + 32 d holds logical chunk lc
-    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
-    const int wc3 = wv >> 1, wm3 = wv & 1;                              // GEMM 3 (all eight waves): 64-channel group x pixel half of 64
-    const int m0 = blockIdx.x * TM;
-
-    auto wg_barrier = [&]() {   // lgkmcnt(0) + s_barrier
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    f32x16 acc3[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.0f;
-    const int a3_row = (wc3 * 64 + l31) * 128, b3_row = (wm3 * 64 + l31) * 128;
-    auto gemm3 = [&](const char* wt3, const char* stage) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int co = ((2 * kk + lh) ^ swz) << 4;
-            half8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *(const half8*)(wt3 + a3_row + i * 4096 + co);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *(const half8*)(stage + b3_row + j * 4096 + co);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc3[i][j], 0, 0, 0);
-        }
-    };
-
-    if (loader) {
-        const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
-        const unsigned wc_off = (unsigned)((rb * PL + lc * 8) * 2), wa_off = (unsigned)((rb * C4 + lc * 8) * 2);
-        auto dma_wc = [&](int oc) {   // W_c rows oc * 64 .. + 63 as four k-tiles [64][128 B]: eight instructions (chunks past the last: out of range)
-            lds_char* const d2 = lds3 + (oc & 1) * WC_BYTES + wave * 1024;
-            const unsigned base = (oc < NOC && !(p.stagger & 4)) ? wc_off + (unsigned)(oc * 64 * PL * 2) : OOB;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, d2 + kt * 8192 + d * 4096, 16, (int)(base + (unsigned)((32 * d * PL + kt * 64) * 2)), 0, 0, 0);
-        };
-        auto dma_wa = [&](int oc) {   // W_a' columns oc * 64 .. + 63 of all 256 rows [256][128 B]: eight instructions
-            lds_char* const d3 = lds3 + WA_OFF + wave * 1024;
-            const unsigned base = (p.stagger & 8) ? OOB : wa_off + (unsigned)(oc * 128);
-#pragma unroll
-            for (int d = 0; d < 8; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, d3 + d * 4096, 16, (int)(base + (unsigned)(32 * d * C4 * 2)), 0, 0, 0);
-        };
-        dma_wc(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier();   // |E(-1)|
-#pragma unroll 1
-        for (int oc = 0; oc < NOC; ++oc) {
-            dma_wa(oc);          // (the one W_a' stage was released by |E(oc - 1)|)
-            dma_wc(oc + 1);      // (its stage was last read before |M(oc - 1)|)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the next W_c tile: this step's W_a' tile has landed
-            wg_barrier();   // |M(oc)|
-            gemm3(lds + WA_OFF, lds + ST_OFF + (oc & (NST - 1)) * ST_BYTES);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's W_c tile has landed
-            wg_barrier();   // |E(oc)|
-        }
-    } else {
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
-        // y rows: a descriptor of exactly M rows (2 KB each; the launcher checks (M + 128) * 2 KB < 4 GiB), rows past it are not written
-        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((unsigned)p.M * (unsigned)(C4 * 2)), 0x00020000);
-        unsigned roff[4], yoff[4];   // this thread's four residual / y rows (residual rows past M read row 0: their results are not stored)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int m = m0 + rb + 32 * d;
-            roff[d] = (unsigned)(((m < p.M ? m : 0) * C4 + lc * 8) * 2);
-            yoff[d] = (unsigned)m * (unsigned)(C4 * 2) + (unsigned)(lc * 16);
-        }
-        auto dma_res = [&](int oc) {   // residual rows of chunk oc into stage oc % 4: four instructions (chunks past the last: out of range)
-            lds_char* const ds = lds3 + ST_OFF + (oc & (NST - 1)) * ST_BYTES + wave * 1024;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, ds + d * 4096, 16, (int)((oc < NOC && !(p.stagger & 1)) ? roff[d] + (unsigned)(oc * 128) : OOB), 0, 0, 0);
-        };
-        dma_res(0); dma_res(1); dma_res(2);
-        // b fragments of this wave's 32 pixels: k-tile kt, 16-deep slice kk -> channels kt * 64 + (2 kk + lh) * 8 .. + 7 of row wave * 32 + l31
-        half8 bf[KT][4];
-        {
-            const int mm = m0 + wave * 32 + l31;
-            const half_t* brow = p.a + (long long)(mm < p.M ? mm : 0) * PL + lh * 8;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) bf[kt][kk] = *(const half8*)(brow + kt * 64 + kk * 16);
-        }
-        // (used here so that the compiler's wait for them stands in front of the loop, not inside it)
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) asm volatile("" :: "v"(bf[kt][kk]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier();   // |E(-1)|
-#pragma unroll 1
-        for (int oc = 0; oc < NOC; ++oc) {
-            const char* const wt2 = lds + (oc & 1) * WC_BYTES;
-            char* const stage = lds + ST_OFF + (oc & (NST - 1)) * ST_BYTES;
-            dma_res(oc + 3);   // (into the stage of step oc - 1, released by |E(oc - 1)|)
-            // GEMM 2: this wave's 32 pixels x the chunk's 64 channels, one 32-channel half at a time (K = 256 out of the b fragments)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x16 acc2;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const half8 fa = *(const half8*)(wt2 + kt * 8192 + (i * 32 + l31) * 128 + (((2 * kk + lh) ^ swz) << 4));
-                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, bf[kt][kk], acc2, 0, 0, 0);
-                    }
-                // y = relu(acc2 + bias_c + x), rounded, in place over the residual in the stage (one lane per element)
-                const int m = wave * 32 + l31;   // pixel within the tile; channels i * 32 + 8 g + 4 lh .. + 3 of the chunk
-                half4 r4[4];
-                half4* q[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = i * 32 + 8 * g + 4 * lh;
-                    q[g] = (half4*)(stage + m * 128 + (((ch >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2);
-                    r4[g] = *q[g];
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = bias_quad(p.bias3, oc * 64 + i * 32 + 8 * g, lh);
-                    half4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc2[4 * g + e] + b4[e];
-                        v = v + (float)r4[g][e];
-                        o[e] = (half_t)fmaxf(v, 0.0f);
-                    }
-                    *q[g] = o;
-                }
-            }
-            wg_barrier();   // |M(oc)|: the y chunk is complete in the stage
-            // the y chunk's whole-row stores out of the stage: four BUFFER stores per wave and step whatever M is
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const u32x4 v = *(const u32x4*)(stage + (rb + 32 * d) * 128 + pc * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, (int)((p.stagger & 2) ? OOB : yoff[d] + (unsigned)(oc * 128)), 0, 0);
-            }
-            gemm3(lds + WA_OFF, stage);
-            // residual(oc + 1) has landed: all but what was issued after it - stores(oc - 2), residual(oc + 2), stores(oc - 1),
-            // residual(oc + 3), stores(oc): five groups of four (in the first steps fewer are outstanding and the wait is trivially met:
-            // the prologue drained residual(0..2))
-            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            wg_barrier();   // |E(oc)|
-        }
-    }
-    // a' = relu(acc3 + bias_a'), rounded, into the (dead) W_c stages as [4 k-tiles][128 rows][128 B]: all eight waves
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch = wc3 * 64 + i * 32 + 8 * g + 4 * lh;
-            const f32x4 b4 = bias_quad(p.bias1n, wc3 * 64 + i * 32 + 8 * g, lh);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = wm3 * 64 + j * 32 + l31;
-                half4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf(acc3[i][j][4 * g + e] + b4[e], 0.0f);
-                *(half4*)(lds + (ch >> 6) * (TM * 128) + m * 128 + ((((ch & 63) >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2) = o;
-            }
-        }
-    wg_barrier();
-    // whole-row stores of a': k-tiles 2 (tid >> 8) and + 1
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-        const int kt = 2 * (tid >> 8) + k2;
-        // (fp8: the channels' reciprocal scales, once per k-tile - read inside the row loop they were re-loaded behind every store)
-        f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
-        if (p.a_next8) { inv0 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8); inv1 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8 + 4); }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int m = m0 + rb + 32 * d;
-            if (m < p.M) {
-                const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
-                if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
-                if (p.a_next8) {   // fp8 precision: a' feeds an fp8 convolution (quantised from the f16-rounded value, as conv_igemm's epilogue)
-                    unsigned lo = 0, hi = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
-                    }
-                    *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// bneck_xn2_f16<TM> - the expand + residual + next-reduce launch as a PIPELINE with one barrier per 64-channel chunk (round 4).
-// bneck_xn_f16 / bneck_xn128_f16 run GEMM 2 and GEMM 3 of a chunk one after the other with a barrier between them: with every
-// memory stream dropped the 128-pixel form still took 132 of its 163 us (tools/study/xn128_ablate.py) - the launch waits for its
-// own two phases per chunk, not for bytes. Here the two GEMMs of DIFFERENT chunks run side by side:
-//   waves 0-3 (P)  step t: GEMM 2 of chunk t (K = 256 out of the wave's b fragments in registers), + bias + residual, ReLU, f16, in
-//                  place into slot t % NS of a ring of stages; they also issue every LDS-DMA: the W_c tile of a later step and the
-//                  residual rows D = NS - 2 steps ahead (one in-order queue per wave: the W_c request goes first, the residual
-//                  request behind it is the only one a step's wait lets stay in flight);
-//   waves 4-7 (C)  step t: GEMM 3 of chunk t - 1 out of slot (t - 1) % NS, the W_a' fragments of that chunk in REGISTERS (plain
-//                  global loads one step ahead: these waves issue no LDS-DMA, so the compiler's own counted waits are right), and
-//                  the y chunk's whole-row stores;
-//   one workgroup barrier per step, NOC + 1 steps. On a SIMD one P and one C wave share the matrix pipe: while one rounds its chunk
-//   into LDS the other multiplies.
-// LDS: W_c ring NWC x 32 KB + stage ring NS x TM x 128 B = 160 KB (TM 128: 2 + 6 stages; TM 64: 3 + 8), W_a' never touches it.
-// Same MFMA products in the same order and the same f32 epilogue operations as the two separate launches: bit-identical.
-template <int TM>
-__global__ __launch_bounds__(512, 1) void bneck_xn2_f16(const BneckParams p) {
-    static_assert(TM == 64 || TM == 128, "pixel tile");
-    constexpr int PL = 256, KT = 4, C4 = 1024, NOC = 16;
-    constexpr int NWC = TM == 128 ? 2 : 3, NS = TM == 128 ? 6 : 8, D = NS - 2, DW = NWC - 1;   // ring sizes, residual / W_c distance in steps
-    constexpr int WC_BYTES = KT * 64 * 128, ST_BYTES = TM * 128, ST_OFF = NWC * WC_BYTES;
-    constexpr int RP = TM / 32;                     // 32-row passes of a stage (LDS-DMA pieces / store pieces per P / C wave and step)
-    constexpr int CT2 = TM == 128 ? 2 : 1;          // 32-channel tiles of the chunk per P wave (TM 128: 32 px x 64 ch; TM 64: 32 px x 32 ch)
-    constexpr int PJ = TM / 32;                     // 32-pixel tiles per C wave (64 channels x all TM pixels)
-    constexpr unsigned OOB = 0xFFFFFF00u;           // past every descriptor's range (the engine keeps them below it)
-    static_assert(ST_OFF + NS * ST_BYTES <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char lds[ST_OFF + NS * ST_BYTES];
-    lds_char* const lds3 = (lds_char*)lds;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wv >= 4;
-    const int wave = wv & 3, lt = tid & 255;
-    const int pc = lt & 7, rb = lt >> 3, lc = pc ^ ((rb >> 1) & 7);     // row-pass role: physical chunk pc of rows rb + 32 d holds logical chunk lc
-    const int l31 = lane & 31, lh = lane >> 5, swz = (l31 >> 1) & 7;
-    const int m0 = blockIdx.x * TM;
-    auto wg_barrier = [&]() {   // lgkmcnt(0) + s_barrier
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    f32x16 acc3[2][PJ];         // C waves: a' rows wave * 64 + i * 32 .., pixels j * 32 ..
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < PJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.0f;
-
-    if (!consumer) {
-        const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
-        const unsigned wc_off = (unsigned)((rb * PL + lc * 8) * 2);
-        unsigned roff[RP];   // this thread's residual rows (rows past M read row 0: their results are not stored)
-#pragma unroll
-        for (int d = 0; d < RP; ++d) {
-            const int m = m0 + rb + 32 * d;
-            roff[d] = (unsigned)(((m < p.M ? m : 0) * C4 + lc * 8) * 2);
-        }
-        auto dma_wc = [&](int oc) {   // W_c rows oc * 64 .. + 63 as four k-tiles [64][128 B] into ring slot oc % NWC: eight instructions
-            lds_char* const d2 = lds3 + (oc % NWC) * WC_BYTES + wave * 1024;
-            const unsigned base = (oc < NOC && !(p.stagger & 4)) ? wc_off + (unsigned)(oc * 64 * PL * 2) : OOB;   // (past the last chunk: out of range, zeros, no traffic)
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, d2 + kt * 8192 + d * 4096, 16, (int)(base + (unsigned)((32 * d * PL + kt * 64) * 2)), 0, 0, 0);
-        };
-        auto dma_res = [&](int oc) {  // residual rows of chunk oc into stage oc % NS: RP instructions
-            lds_char* const ds = lds3 + ST_OFF + (oc % NS) * ST_BYTES + wave * 1024;
-#pragma unroll
-            for (int d = 0; d < RP; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, ds + d * 4096, 16, (int)((oc < NOC && !(p.stagger & 1)) ? roff[d] + (unsigned)(oc * 128) : OOB), 0, 0, 0);
-        };
-#pragma unroll
-        for (int oc = 0; oc < DW; ++oc) dma_wc(oc);
-#pragma unroll
-        for (int oc = 0; oc < D; ++oc) dma_res(oc);
-        // b fragments of this wave's 32 pixels: k-tile kt, 16-deep slice kk -> channels kt * 64 + (2 kk + lh) * 8 .. + 7 of its row
-        const int pg = TM == 128 ? wave : (wave & 1), cg = TM == 128 ? 0 : (wave >> 1);   // pixel group of 32, 32-channel half (TM 64)
-        half8 bf[KT][4];
-        {
-            const int mm = m0 + pg * 32 + l31;
-            const half_t* brow = p.a + (long long)(mm < p.M ? mm : 0) * PL + lh * 8;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) bf[kt][kk] = *(const half8*)(brow + kt * 64 + kk * 16);
-        }
-        // (used here so that the compiler's wait for them stands in front of the loop, not inside it)
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) asm volatile("" :: "v"(bf[kt][kk]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wg_barrier();   // step -1: W_c(0 .. DW - 1) and the residual rows of chunks 0 .. D - 1 are in LDS
-#pragma unroll 1
-        for (int t = 0; t <= NOC; ++t) {
-            dma_wc(t + DW);      // (ring slot of W_c(t - 1): last read before the barrier of step t - 1)
-            dma_res(t + D);      // (stage of chunk t - 2: its GEMM 3 and its stores ended with step t - 1)
-            if (t < NOC) {
-                const char* const wt2 = lds + (t % NWC) * WC_BYTES;
-                char* const stage = lds + ST_OFF + (t % NS) * ST_BYTES;
-#pragma unroll
-                for (int i = 0; i < CT2; ++i) {
-                    const int c0 = (cg * CT2 + i) * 32;   // this tile's first channel within the chunk
-                    f32x16 acc2;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
-                    if (!(p.stagger & 16)) {
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const half8 fa = *(const half8*)(wt2 + kt * 8192 + (c0 + l31) * 128 + (((2 * kk + lh) ^ swz) << 4));
-                            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, bf[kt][kk], acc2, 0, 0, 0);
-                        }
-                    }
-                    if (p.stagger & 64) continue;
-                    // y = relu(acc2 + bias_c + x), rounded, in place over the residual in the stage (one lane per element)
-                    const int m = pg * 32 + l31;
-                    half4 r4[4];
-                    half4* q[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = c0 + 8 * g + 4 * lh;
-                        q[g] = (half4*)(stage + m * 128 + (((ch >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2);
-                        r4[g] = *q[g];
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = bias_quad(p.bias3, t * 64 + c0 + 8 * g, lh);
-                        half4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc2[4 * g + e] + b4[e];
-                            v = v + (float)r4[g][e];
-                            o[e] = (half_t)fmaxf(v, 0.0f);
-                        }
-                        *q[g] = o;
-                    }
-                }
-            }
-            // what the next step needs of this wave's requests: W_c(t + 1) (all but the newest DW - 1 tiles) and, older than that,
-            // residual(t + 1); only the residual pieces just issued (and the newer W_c tiles) may stay in flight
-            // (after the last step everything has to have landed: the consumers write a' over the W_c ring next)
-            if (t == NOC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (DW == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP + 8) : "memory");
-            wg_barrier();
-        }
-    } else {
-        // ---- consumers: a'[64 ch x TM px per wave] += W_a'[rows, chunk] x y chunk, one step behind the producers
-        const half_t* const arow = p.w1n + (long long)(wave * 64 + l31) * C4 + lh * 8;   // fragment (i, kk) of chunk c: + i * 32 * C4 + c * 64 + kk * 16
-        half8 fa[2][2][4];       // [buffer][i][kk]
-        auto load_a = [&](int c, int buf) {
-            const int cc = c < NOC ? c : NOC - 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fa[buf][i][kk] = *(const half8*)(arow + (long long)i * 32 * C4 + cc * 64 + kk * 16);
-        };
-        long long yrow[RP];
-#pragma unroll
-        for (int d = 0; d < RP; ++d) yrow[d] = (long long)(m0 + rb + 32 * d) * C4 + lc * 8;
-        load_a(0, 0);
-        wg_barrier();            // step -1
-        wg_barrier();            // step 0: the producers' first chunk
-        auto consume = [&](int c, int buf) {
-            const char* const stage = lds + ST_OFF + (c % NS) * ST_BYTES;
-            if (!(p.stagger & 8)) load_a(c + 1, buf ^ 1);
-#pragma unroll
-            for (int d = 0; d < RP; ++d) {
-                const half8 v = *(const half8*)(stage + (rb + 32 * d) * 128 + pc * 16);
-                if (m0 + rb + 32 * d < p.M && !(p.stagger & 2)) *(half8*)(p.y + yrow[d] + c * 64) = v;
-            }
-            if (!(p.stagger & 32))
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((2 * kk + lh) ^ swz) << 4;
-                half8 fb[PJ];
-#pragma unroll
-                for (int j = 0; j < PJ; ++j) fb[j] = *(const half8*)(stage + (j * 32 + l31) * 128 + co);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < PJ; ++j) acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i][kk], fb[j], acc3[i][j], 0, 0, 0);
-            }
-            wg_barrier();
-        };
-#pragma unroll 1
-        for (int c = 0; c < NOC; c += 2) { consume(c, 0); consume(c + 1, 1); }
-    }
-    // a' = relu(acc3 + bias_a'), rounded, into the (dead) W_c ring as [4 k-tiles][TM rows][128 B] (the consumer waves hold it all)
-    if (consumer) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = wave * 64 + i * 32 + 8 * g + 4 * lh;
-                const f32x4 b4 = bias_quad(p.bias1n, wave * 64 + i * 32 + 8 * g, lh);
-#pragma unroll
-                for (int j = 0; j < PJ; ++j) {
-                    const int m = j * 32 + l31;
-                    half4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (half_t)fmaxf(acc3[i][j][4 * g + e] + b4[e], 0.0f);
-                    *(half4*)(lds + (ch >> 6) * (TM * 128) + m * 128 + ((((ch & 63) >> 3) ^ ((m >> 1) & 7)) << 4) + (ch & 4) * 2) = o;
-                }
-            }
-    }
-    wg_barrier();
-    // whole-row stores of a': all eight waves, k-tiles 2 (tid >> 8) and + 1
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-        const int kt = 2 * (tid >> 8) + k2;
-        // (fp8: the channels' reciprocal scales, once per k-tile - read inside the row loop they were re-loaded behind every store)
-        f32x4 inv0 = { 0.0f, 0.0f, 0.0f, 0.0f }, inv1 = inv0;
-        if (p.a_next8) { inv0 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8); inv1 = *(const f32x4*)(p.a_next8_inv + kt * 64 + lc * 8 + 4); }
-#pragma unroll
-        for (int d = 0; d < RP; ++d) {
-            const int m = m0 + rb + 32 * d;
-            if (m < p.M) {
-                const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
-                if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
-                if (p.a_next8) {   // fp8 precision: a' feeds an fp8 convolution (quantised from the f16-rounded value, as conv_igemm's epilogue)
-                    unsigned lo = 0, hi = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
-                    }
-                    *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
-                }
-            }
-        }
-    }
-}
-
 const char* bneck_symbol(int planes, int tm, bool next, bool dual) {
-    if (planes == 256) return tm == 128 ? "bneck_xn128_f16" : (tm == 64 ? "bneck_xn_f16" : (tm == 1128 ? "bneck_xn2_f16<128>" : "bneck_xn2_f16<64>"));   // (tm + 1000: the pipelined form)
+    if (planes == 256) return "bneck_xn_f16";
     if (dual) return "bneck_chain_f16<64,128,next,dual>";
     if (planes == 64 && tm == 128) return next ? "bneck_chain_f16<64,128,next>" : "bneck_chain_f16<64,128>";
     if (planes == 64) return tm == 256 ? (next ? "bneck_chain_f16<64,256,next>" : "bneck_chain_f16<64,256>") : (next ? "bneck_chain_f16<64,64,next>" : "bneck_chain_f16<64,64>");
@@ -1089,19 +606,11 @@ const char* bneck_symbol(int planes, int tm, bool next, bool dual) {
 hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream) {
     if (p.M < 1 || (p.stride != 1 && p.stride != 2)) return hipErrorInvalidValue;
     const int ntiles = (p.M + tm - 1) / tm;
-    const int slots = p.grid_cap > 0 ? p.grid_cap : ntiles;
-    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
+    const dim3 grid((unsigned)ntiles);
     const bool next = p.a_next != nullptr;
     if (p.no_b) {   // expand conv + residual + next reduce conv of a 256-plane block; b is a tensor (p.a)
-        if (planes != 256 || (tm != 64 && tm != 128 && tm != 1064 && tm != 1128) || p.x2 || !p.res || !p.w1n || (!p.a_next && !p.a_next8) || p.grid_cap) return hipErrorInvalidValue;
-        if (tm > 1000) {   // the pipelined form (bneck_xn2_f16): tm - 1000 pixels per tile
-            const dim3 g2((unsigned)((p.M + (tm - 1000) - 1) / (tm - 1000)));
-            if (tm == 1128) hipLaunchKernelGGL(bneck_xn2_f16<128>, g2, dim3(512), 0, stream, p);
-            else hipLaunchKernelGGL(bneck_xn2_f16<64>, g2, dim3(512), 0, stream, p);
-        } else if (tm == 128) {   // (its y stores go through a 32-bit buffer descriptor of M rows of 2 KB, offsets up to one tile past it)
-            if (((unsigned long long)p.M + 128ull) * 2048ull >= 0xFFFFFFFFull) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(bneck_xn128_f16, grid, dim3(512), 0, stream, p);
-        } else hipLaunchKernelGGL(bneck_xn_f16, grid, dim3(512), 0, stream, p);
+        if (planes != 256 || tm != 64 || p.x2 || !p.res || !p.w1n || (!p.a_next && !p.a_next8)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bneck_xn_f16, grid, dim3(512), 0, stream, p);
         return hipGetLastError();
     }
     if (p.x2) {   // the stage's first block (two-source expand conv): 64 planes, 64-channel second source, 128-pixel tiles

@@ -35,7 +35,6 @@ struct cmax { static constexpr int v = A > B ? A : B; };
 // STAGES == 3: ring of three; the DMA of step k+2 is issued while step k computes, each step waits
 //              only for ITS tile with a counted s_waitcnt vmcnt(N) (N = this wave's DMA instructions
 //              per tile) and a raw s_barrier, so one tile stays in flight across every barrier.
-//              (STAGES == 4: the same with two tiles in flight; measured neutral, kept as a switch.)
 // ML: multi-level input - the rows of an image are the cells of up to five pyramid levels laid end
 //              to end; every staged row carries its own level's height and width, so a tap never
 //              leaves the level (the shared prediction head as one launch over the whole pyramid).
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     constexpr int LDS_BYTES = cmax<RING_BYTES, TAIL ? TM * 512 : (TM / EPI) * ES * 4>::v;
     static_assert(WM % EPI == 0, "epilogue split");
     static_assert((NW == 4 || NW == 8) && WTC % MT == 0 && WTM % MT == 0 && (MT == 32 || MT == 16) && TM % RSTEP == 0 && TCH % RSTEP == 0, "tile shape");
-    static_assert(STAGES == 1 || STAGES == 2 || ((STAGES == 3 || STAGES == 4) && !SMALLC), "ring variants: no ordinary loads may share the loop");
+    static_assert(STAGES == 1 || STAGES == 2 || (STAGES == 3 && !SMALLC), "ring variants: no ordinary loads may share the loop");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -354,50 +353,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
             __syncthreads();
             cur ^= 1;
         }
-    } else if constexpr (STAGES == 3 && FP8) {
-        // fp8 operands on a ring of three stages, TWO tiles in flight (round 4): for launches of about one workgroup per CU
-        // (YOLACT-700 R101 at 8 frames: 242 tiles of 128 x 128) the two-stage form exposes one L2 round trip per k-step, and the
-        // 64 x 64 tiles that hid it by occupancy are bound by the CU's L2 -> LDS path instead (16 KB per 1 MFLOP-step: 25 B/clk/CU =
-        // 830 TFLOP/s, measured). Per step: wait for THIS tile (counted: the next may stay in flight), barrier, request the tile
-        // after next into the stage the previous step read, operands, MFMAs. Same products in the same order as the two-stage form.
-        static_assert(MT == 16 && !SMALLC && !SPLITK && TC % 2 == 0, "fp8 form: 16x16x128, ordinary channels");
-        typedef int v8i __attribute__((ext_vector_type(8)));
-        auto read_op = [&](const char* row) {
-            const u32x4 lo = *(const u32x4*)(row + (((2 * lh) ^ swz) << 4)), hi = *(const u32x4*)(row + (((2 * lh + 1) ^ swz) << 4));
-            v8i v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = (int)lo[e]; v[4 + e] = (int)hi[e]; }
-            return v;
-        };
-        const int nk = nk_total;
-        load_tile(0);
-        if (nk > 1) load_tile(1);
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's operand reads of the previous tile are in registers
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 2 < nk) load_tile(st == 0 ? 2 : st - 1);   // stage (kt + 2) % 3 = the stage of tile kt - 1
-            const char* base = lds + st * AB_BYTES;
-            v8i b[TMT];
-#pragma unroll
-            for (int j = 0; j < TMT; ++j) b[j] = read_op(base + b_row + j * TSTR);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                v8i a[TC / 2];
-#pragma unroll
-                for (int i = 0; i < TC / 2; ++i) a[i] = read_op(base + a_row + (hh * (TC / 2) + i) * TSTR);
-#pragma unroll
-                for (int i = 0; i < TC / 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMT; ++j)
-                        acc[hh * (TC / 2) + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[hh * (TC / 2) + i][j], 0, 0, 0, 127, 0, 127);
-            }
-            st = st == 2 ? 0 : st + 1;
-        }
-        __syncthreads();  // LDS is reused by the epilogue
     } else if (STAGES == 1) {
         // One LDS stage, no overlap inside the workgroup: for the HBM-bound 1x1 layers (K <= 256, one to
         // four steps) what hides latency is the number of workgroups per CU, and 34 KB of LDS (with the
@@ -633,8 +588,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                 }
         }
         __syncthreads();
-        f32x4 s0[SPLITK ? NPASS : 1], s1[SPLITK ? NPASS : 1];   // (split-K, in-launch reduction: the tile's summed rows)
-        if (SPLITK) {
+        if (SPLITK) {   // the raw f32 partial tile -> this K slice's slab; splitk_reduce_f16 sums the slabs in slice order and runs the epilogue
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
@@ -644,49 +598,14 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     *(f32x4*)(dst + 4) = *(const f32x4*)(E + m_l * ES + ch_l + 4);
                 }
             }
-            if (!p.tile_cnt) return;   // splitk_reduce_f16 finishes the convolution
-            // In-launch reduction (the counter form of the guide's split-K recipe): every wave's slab stores have completed, ONE lane
-            // releases them at agent scope and draws a ticket; the workgroup that draws the last one acquires, sums the tile's slabs
-            // in slice order (the order of splitk_reduce_f16: the bits are the same) and runs the epilogue. Nobody waits for
-            // anybody: a workgroup that is not last is done. The counter goes back to zero for the next launch that uses it
-            // (launches that share counters are ordered on one stream).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();   // (also: every read of E is over - its first word now carries the verdict)
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned ticket = __hip_atomic_fetch_add(p.tile_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = ticket == (unsigned)(p.k_slices - 1);
-                if (last) {
-                    __hip_atomic_store(p.tile_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                *(volatile int*)lds = last;
-            }
-            __syncthreads();
-            if (!*(volatile int*)lds) return;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) { s0[pass] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; s1[pass] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; }
-            const long long slab = (long long)p.M * p.partial_ld;
-            for (int sl = 0; sl < p.k_slices; ++sl) {
-#pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass) {   // (NPASS rows' loads in flight per slice)
-                    const int m = m_tile * TM + pass * RPP + rr;
-                    const float* src = p.partial + sl * slab + (long long)(m < p.M ? m : 0) * p.partial_ld + ch;
-                    s0[pass] += *(const f32x4*)src;
-                    s1[pass] += *(const f32x4*)(src + 4);
-                }
-            }
+            return;
         }
         if (ch_ok) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m_l = pass * RPP + rr, m = m_tile * TM + h * EROWS + m_l;
                 if (m < p.M) {
-                    f32x4 v0, v1;
-                    if (SPLITK) { v0 = s0[pass]; v1 = s1[pass]; }
-                    else { v0 = *(const f32x4*)(E + m_l * ES + ch_l); v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4); }
+                    const f32x4 v0 = *(const f32x4*)(E + m_l * ES + ch_l), v1 = *(const f32x4*)(E + m_l * ES + ch_l + 4);
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -696,7 +615,6 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     long long yo, ro;
                     offsets(m, yo, ro);
                     if (p.res) {
-                        if (SPLITK) rv[pass] = load_residual<true>(p, m, ch, ro);   // (the reducer asks for its residual rows here; p.res_up is looked at at run time, as splitk_reduce_f16 does)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[pass][e];
                     }
@@ -970,12 +888,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 }
 
 int conv_tile_ch(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64;
-                 case TILE_32x256: case TILE_DIRECT32: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_FP8: return 64;
+                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_S4: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x128_FP8_S3: return 128; case TILE_64x64_S3: case TILE_64x64_S4: case TILE_64x64_FP8: return 64; case TILE_DIRECT32: return 32; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: return 128; case TILE_64x64_S3: case TILE_64x64_FP8: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -989,7 +907,6 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_128x128_M16: return "conv_igemm_f16<128,128,2,2,0,2,mfma16>";
         case TILE_128x128_S3_M16: return "conv_igemm_f16<128,128,2,2,0,3,mfma16>";
         case TILE_128x128_S3: return "conv_igemm_f16<128,128,2,2,0,3>";
-        case TILE_128x128_S4: return "conv_igemm_f16<128,128,2,2,0,4>";
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
         case TILE_64x64_S3: return "conv_igemm_f16<64,64,2,2,0,3>";
         case TILE_128x128_K1: return "conv_igemm_f16<128,128,2,2,0,1>";
@@ -997,9 +914,6 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_128x128_FP8: return "conv_igemm_fp8<128,128,2,2>";
         case TILE_64x64_FP8: return "conv_igemm_fp8<64,64,2,2>";
-        case TILE_128x128_FP8_S3: return "conv_igemm_fp8<128,128,2,2,ring3>";
-        case TILE_64x64_S4: return "conv_igemm_f16<64,64,2,2,0,4>";
-        case TILE_DIRECT32: return "conv_direct_f16<8>";
     }
     return "?";
 }
@@ -1012,7 +926,6 @@ hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream) {
 
 // One kernel launch (for split-K: the main kernel only).
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
-    if (tile == TILE_DIRECT32) return launch_conv_direct(p, stream);
     const int tm = conv_tile_m(tile);
     const int n_m_tiles = (p.M + tm - 1) / tm - p.m_tile0;
     if (n_m_tiles < 1) return hipErrorInvalidValue;
@@ -1081,9 +994,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
     if (p.k_slices > 1) {   // split-K main kernel; launch_splitk_reduce finishes it
         const dim3 gk((unsigned)(n_m_tiles * p.n_ch_tiles * p.k_slices));
         if (tile == TILE_128x128_S3) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);
-        else if (tile == TILE_128x128_S4) hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1, true>), gk, dim3(256), 0, stream, p);
         else if (tile == TILE_64x64_S3) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, true>), gk, dim3(256), 0, stream, p);
-        else if (tile == TILE_64x64_S4) hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1, true>), gk, dim3(256), 0, stream, p);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -1093,9 +1004,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
             case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
-            case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
-            case TILE_64x64_S4: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1, false, 32, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, false, false, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_256x256_M16: hipLaunchKernelGGL((conv_igemm_f16<256, 256, 2, 4, false, 2, 2, false, 16, false, false, true>), grid, dim3(512), 0, stream, p); break;
@@ -1116,9 +1025,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_64x256_SMALLC: hipLaunchKernelGGL((conv_igemm_f16<64, 256, 1, 4, true, 2, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
-        case TILE_128x128_S4: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_64x64_S3: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 3, 1>), grid, dim3(256), 0, stream, p); break;
-        case TILE_64x64_S4: hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 4, 1>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x256_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 2, 2, false, 16>), grid, dim3(512), 0, stream, p); break;
         case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
         case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16>), grid, dim3(256), 0, stream, p); break;
@@ -1135,10 +1042,6 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
         case TILE_64x64_FP8:     // ... and with at most two 128 x 128 tiles per CU: sixteen times the workgroups
             if (!p.scale) return hipErrorInvalidValue;
             hipLaunchKernelGGL((conv_igemm_f16<64, 64, 2, 2, false, 2, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
-            break;
-        case TILE_128x128_FP8_S3:   // ... or, for about one 128 x 128 tile per CU, the ring of three (two tiles in flight)
-            if (!p.scale) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, false, true>), grid, dim3(256), 0, stream, p);
             break;
         default: return hipErrorInvalidValue;
     }

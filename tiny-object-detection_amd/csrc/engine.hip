@@ -15,7 +15,7 @@
 
 #include <algorithm>
 #include <map>
-#include <mutex>
+#include <atomic>
 #include <set>
 #include <string>
 #include <vector>
@@ -34,6 +34,7 @@ const RoctxApi& roctx_api() {   // resolved once per process (C++11 static initi
     }();
     return api;
 }
+SetupAudit& setup_audit() { static SetupAudit a; return a; }
 }  // namespace yh
 
 namespace {
@@ -130,7 +131,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 // The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
-        t64_minsteps, t64_s4, s4, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain, xn_tm, xn_pipe, fp8_s3, splitk_inl, direct;
+        t64_minsteps, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain;
 };
 static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     auto d = [](int v, int def) { return v < 0 ? def : v; };
@@ -139,11 +140,10 @@ static Tune resolve_tuning(const yh_tuning& t, int device_cus) {
     r.mfma16 = d(t.mfma16, 1); r.t128x256_m16 = d(t.t128x256_m16, 1); r.small16 = d(t.small16, 0); r.bigk = d(t.bigk, 256);
     r.tailsplit = d(t.tailsplit, 1); r.chsplit = d(t.chsplit, 1); r.k1tile = d(t.k1tile, 6); r.k1_maxk = d(t.k1_maxk, 1024);
     r.splitk_minsteps = d(t.splitk_minsteps, 12); r.t64 = d(t.t64, 2); r.t64_maxb = d(t.t64_maxb, 256); r.t64_minsteps = d(t.t64_minsteps, 24);
-    r.t64_s4 = d(t.t64_s4, 0); r.s4 = d(t.s4, 0); r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
+    r.stemfuse = d(t.stemfuse, 1); r.prefuse = d(t.prefuse, 1); r.headmerge = d(t.headmerge, 1);
     r.upfuse = d(t.upfuse, 1); r.k1_generic = d(t.k1_generic, 0); r.ablate = d(t.ablate, 0); r.op_tile = t.op_tile; r.op_kslices = d(t.op_kslices, 0);
     r.tailfork = d(t.tailfork, 1); r.dsfuse = d(t.dsfuse, 1); r.headfork_maxb = d(t.headfork_maxb, 1 << 20); r.protofuse = d(t.protofuse, 1); r.k1_min1 = d(t.k1_min1, 8); r.k1_min3 = d(t.k1_min3, 10);
     r.chain = d(t.chain, 17);
-    r.xn_tm = t.xn_tm; r.xn_pipe = d(t.xn_pipe, 0); r.fp8_s3 = d(t.fp8_s3, 0); r.splitk_inl = d(t.splitk_inl, 0); r.direct = d(t.direct, 0);
     return r;
 }
 
@@ -221,6 +221,7 @@ struct yh_engine {
     static const size_t kSplitKBytes = (size_t)48 << 20;
 
     bool weights_loaded = false, capturing = false;
+    bool worker_mode = false;   // the handle is a group member being driven from its worker thread: no capture, no allocation there
     unsigned* side_word = nullptr;   // target of the captured side-branch memset (enqueue_all)
     uint8_t* blob_dev = nullptr;   // the canonical blob as loaded (send / receive buffer of the RCCL weight broadcast)
     int cur_n = 0;
@@ -233,16 +234,21 @@ struct yh_engine {
     int tail_fork_op = 0;   // ops[tail_fork_op..] (the protonet) do not feed the tail's K1-K3
     int head_fork_op = 0;   // ops[head_fork_op .. tail_fork_op) are the shared prediction head; the protonet does not read them
     float* splitk_ws_side = nullptr;   // split-K workspace of convolutions launched on the side stream
-    // In-launch split-K reduction (tune.splitk_inl): arrival counters per output tile, zero between launches - one array per stream
-    // that carries split-K convolutions (launches on one stream are ordered, so they share theirs).
-    static constexpr int kSplitKTiles = 4096;
-    unsigned* splitk_cnt = nullptr;
-    unsigned* splitk_cnt_side = nullptr;
     std::map<int, hipGraphExec_t> graphs;  // key = n*2 + with_tail
     std::vector<std::string> prof_labels;  // storage behind the names yh_profile_run returns
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
+
+namespace yh {
+void engine_set_worker_mode(yh_engine* h, bool on) { h->worker_mode = on; }
+bool engine_uses_graph(const yh_engine* h) { return h->cfg.use_graph != 0; }
+bool engine_step_prepared(const yh_engine* h, int n_frames, int with_tail) {
+    if (!h->cfg.use_graph) return true;
+    const int key0 = (n_frames * 2 + (with_tail ? 1 : 0)) * 2;
+    return h->graphs.count(key0) && h->graphs.count(key0 | 1);
+}
+}  // namespace yh
 
 #define HIPCHK(h, call)                                                                        \
     do {                                                                                       \
@@ -794,10 +800,9 @@ ConvTile pick_tile_base(const Tune& tu, const Panel& pn, int M, int stride, int 
 // ml: the op has a multi-level input (only the tiles launch_conv instantiates for it may be chosen)
 ConvTile pick_tile(const Tune& tu, const Panel& pn, int M, int stride = 0, int pad = 0, bool ml = false) {
     const ConvTile t = pick_tile_base(tu, pn, M, stride, pad, ml);
-    if (tu.s4 && !ml && t == TILE_128x128_S3) return TILE_128x128_S4;   // A/B: ring of four for the latency-bound tile
     // Latency-bound launches with few 128 x 128 tiles: 64 x 64 tiles put four times as many workgroups on
     // the idle CUs and a K step costs a wave 4 MFMAs instead of 16 (tune.t64; 0 = off)
-    if (tu.t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= tu.t64_maxb) return tu.t64_s4 && !ml ? TILE_64x64_S4 : TILE_64x64_S3;
+    if (tu.t64 && t == TILE_128x128_S3 && (long long)((M + 127) / 128) * (pn.coutPad / 128) <= tu.t64_maxb) return TILE_64x64_S3;
     // 128 x 256: the 2-stage 16x16x32 form measures ~5 % faster than the 3-stage 32x32x16 ring on stride-1
     // layers (0.112 vs 0.118 ms on the 69 x 69 3x3 convs at batch 64) and slower on the stride-2 one
     if (tu.t128x256_m16 && t == TILE_128x256 && stride == 1) return TILE_128x256_M16;
@@ -879,9 +884,8 @@ int tail_split_tiles(const Tune& tu, int coutPad, const ConvParams& p, ConvTile 
 struct KLaunch { bool reduce; ConvParams p; ConvTile tile; double frac; const char* what; };
 
 int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
-    if (p.k_slices > 1) {   // split-K: main kernel + slab reduction (inside the main kernel where p.tile_cnt is set)
+    if (p.k_slices > 1) {   // split-K: main kernel + slab reduction
         out[0] = KLaunch{ false, p, tile, 1.0, "/splitk" };
-        if (p.tile_cnt) return 1;
         out[1] = KLaunch{ true, p, tile, 0.0, "" };
         return 2;
     }
@@ -935,8 +939,6 @@ hipError_t launch_conv_planned(const Tune& tu, const ConvParams& p, ConvTile til
 ConvTile dual_conv_tile(ConvTile t) {
     switch (t) {
         case TILE_128x128: case TILE_128x128_K1: case TILE_128x128_S3: case TILE_64x64_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_256x256_M16: return t;
-        case TILE_128x128_S4: return TILE_128x128_S3;
-        case TILE_64x64_S4: return TILE_64x64_S3;
         case TILE_256x256: return TILE_256x256_M16;
         default: return TILE_128x128;
     }
@@ -980,15 +982,6 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
     if (h->tune.ablate & 4) { p.skip_dma = 1; }
     ConvTile tile = pick_tile(h->tune, pn, p.M, o.stride, o.pad, o.nlev > 0);
     if (o.dual) tile = dual_conv_tile(tile);
-    // tune.direct (opt-in, measured neutral): the smallest launches of a small-batch step - at most tune.direct workgroups of 32 x 32
-    // and 24-36 k-steps: layer 4's 1x1 reductions, lat5, P5-P7 at batch 1 - on the register-fed tiles of conv_direct.hip: the K split
-    // stays inside the workgroup, there is no slab and no reduce launch. Per launch (event-bracketed, batch 1): those six 12.2-13.6 us
-    // against 13.6-17.4 for the tiled launch + reduce; every larger launch SLOWER (a 312-workgroup layer-3 3x3: 20.5 against 17.0; its
-    // 1x1 neighbours 10.3-12.5 against 7.5-10.5; the 69 x 69 FPN / protonet 3x3: 44 against 20) - a workgroup that streams (32 + 32) x K
-    // operand rows alone is bound by its own memory latency, where the tiled form splits K over six workgroups. The step: 0.7127 ms
-    // with direct = 192, 0.7107 without (batch 2: 0.9365 / 0.9325, batch 4: 1.2739 / 1.2700): not a gain, so the default is off.
-    if (h->tune.direct > 0 && !h->fp8_active && (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && conv_direct_ok(p) && ((p.ksteps >= 24 && p.ksteps <= 36) || h->tune.direct >= (1 << 20) /* study: every eligible launch */) &&
-        (long long)((p.M + 31) / 32) * (pn.coutPad / 32) <= h->tune.direct) tile = TILE_DIRECT32;
     if (h->fp8_active) {
         // fp8 precision, calibrated: what this op's output is written as, and (for the K-heavy 3x3 layers) E4M3 operands
         p.y = o.write_f16 ? o.out.d : nullptr;
@@ -1009,8 +1002,6 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
             // a K step of 128 costs a wave 4 MFMAs instead of 16 and four times as many workgroups share the CUs)
             const long long b128 = (long long)((p.M + 127) / 128) * (pn.coutPad / 128);
             if (tile == TILE_128x128_FP8 && o.nlev == 0 && h->tune.t64 && b128 <= 2ll * h->tune.plan_cus) tile = TILE_64x64_FP8;
-            // (round 4, tune.fp8_s3: about one 128 x 128 tile per CU - more than half a round, at most one - on the ring of three stages)
-            if (tile == TILE_64x64_FP8 && h->tune.fp8_s3 && b128 <= h->tune.plan_cus && 2 * b128 > h->tune.plan_cus) tile = TILE_128x128_FP8_S3;
         }
     }
     if (tile_out) *tile_out = tile;
@@ -1025,8 +1016,8 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
         p.y = nullptr; p.y8 = nullptr;
     }
     const int splitk_min = h->tune.splitk_minsteps, t64_mode = h->tune.t64, t64_min = h->tune.t64_minsteps;
-    const bool ring128 = tile == TILE_128x128_S3 || tile == TILE_128x128_S4;
-    const bool ring64 = (tile == TILE_64x64_S3 || tile == TILE_64x64_S4) && t64_mode >= 2;
+    const bool ring128 = tile == TILE_128x128_S3;
+    const bool ring64 = tile == TILE_64x64_S3 && t64_mode >= 2;
     // (launches of at most 32 output pixels - P6 / P7 at batch 1: 25 and 9 - do not split: four workgroups walking 36 k-steps take
     // as long as their slices plus the reduce launch, and the step has two launches fewer)
     if (p.M > 32 && ((ring128 && p.ksteps >= splitk_min) || (ring64 && p.ksteps >= t64_min))) {
@@ -1043,7 +1034,6 @@ int fill_conv_params(yh_engine* h, const Op& o, int n, ConvParams* out, ConvTile
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = pn.coutPad;
             p.partial = h->splitk_ws;
-            if (h->tune.splitk_inl && tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
     }
     if (p.ldy < p.cout8 || o.in.c != pn.cin_store) return h->fail(YH_EINVAL, "conv buffer geometry mismatch at " + o.name);
@@ -1087,8 +1077,7 @@ bool chain_active(const yh_engine* h, const Op& ob, int n) {
 }
 int chain_tile_m(const yh_engine* h, const Op& ob, int n) {
     if (h->ops[ob.chain_c].dual) return ((long long)n * ob.P * ob.Q >= 8ll * h->tune.plan_cus * 128 || (h->tune.chain & 16)) ? 128 : 0;   // (one tile size; 0: inactive)
-    // (tune.chain bit 1, A/B: 128-pixel tiles for the 64-plane chains: 48 KB of LDS and 160 VGPRs - three workgroups per CU)
-    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? ((h->tune.chain & 2) ? 128 : 256) : 128;
+    const int planes = h->panels[ob.panel].cout, big = planes == 64 ? 256 : 128;
     const long long M = (long long)n * ob.P * ob.Q;
     // The big tiles from about four rounds of two workgroups per CU on: measured, the chain gains 1.6 % of a batch-64 step (9.3
     // rounds in layer 1) and LOSES 1.3 % at batch 16 (2.3 rounds: the long-lived workgroups' tail outweighs the saved traffic).
@@ -1118,11 +1107,6 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
         if (pa.Kpad != 4 * pb.cout || pa.cout != pb.cout) return h->fail(YH_EINVAL, "bottleneck chain: next conv geometry mismatch at " + oa.name);
         p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias; p.a_next = oa.out.d;
     }
-    // One workgroup per tile (measured best: 9.64 ms per batch-64 step against 9.87 unfused). A/B forms kept behind tune.chain:
-    // bit 2 a persistent grid of two workgroups per CU (9.67), bit 3 (with bit 2) the second-dispatched half started late so
-    // that co-resident workgroups sit in opposite phases (9.77: the idle start costs more than the offset buys).
-    if (h->tune.chain & 4) p.grid_cap = 2 * h->tune.plan_cus;
-    if ((h->tune.chain & 8) && p.grid_cap > 0) p.stagger = (h->tune.chain >> 8) ? (h->tune.chain >> 8) * 64 : 704;   // ~21 us at 2.1 GHz: half a tile
     *out = p;
     return YH_OK;
 }
@@ -1130,7 +1114,7 @@ int fill_bneck_params(yh_engine* h, const Op& ob, int n, BneckParams* out) {
 // The no-3x3 form (bneck.hip: NOB): does the expand conv `oc` of a 256-plane identity block also run the next block's reduce conv
 // at batch n? One eight-wave workgroup per CU and 64-pixel tiles: for launches of about one tile per CU, where the two separate
 // launches are latency bound (YOLACT-700 R101 at 8 frames: 22 + 25 us -> one launch of 40). tune.chain bit 7 turns it off.
-// Returns the launch's pixel tile: 0 (the two convolutions stay separate launches), 64 or 128.
+// Returns the launch's pixel tile: 0 (the two convolutions stay separate launches) or 64.
 int xn_tile(const yh_engine* h, const Op& oc, int n) {
     if (!(h->tune.chain & 1) || (h->tune.chain & 128) || oc.xn_a < 0 || n < 1 || oc.kind != OP_CONV) return 0;
     const Panel& pc = h->panels[oc.panel];
@@ -1142,8 +1126,7 @@ int xn_tile(const yh_engine* h, const Op& oc, int n) {
     if (pa.k != 1 || pa.Kpad != 1024 || pa.cout != 256 || oa.stride != 1 || oa.dual || oa.has_res || oa.act != 1 || oa.out.c != 256 || oa.out.img_stride != pq * 256) return 0;
     if (oa.in.d != oc.out.d) return 0;
     if (h->fp8_active && (oc.fp8 || oa.fp8 || oc.write_q || !oc.write_f16)) return 0;
-    const bool fits128 = (M + 128) * 2048 < 0xFFFFFFFFll;   // (the 128-pixel form stores y through a 32-bit buffer descriptor)
-    if (h->tune.xn_tm == 64 || (h->tune.xn_tm == 128 && fits128)) return h->tune.xn_tm;   // tests / A-B: this form wherever the launch is eligible
+    if (h->tune.chain & 2) return 64;   // tests: this form wherever the launch is eligible (it reaches the kernel with small tensors)
     // 64-pixel tiles (eight waves, dedicated loader waves): one round of tiles and at least half a round - measured per step,
     // interleaved (tools/study/xn_ab_c4.py, tools/ab_tune.py): YOLACT-700 R101 fp8 at 8 frames (242 tiles) 3.242 -> 3.089 ms;
     // YOLACT-550 R50 at batch 8 (154) 1.887 -> 1.876; but batch 4 (77) 1.252 -> 1.272, batch 16 (307: two rounds) 3.076 -> 3.085, R101
@@ -1151,10 +1134,8 @@ int xn_tile(const yh_engine* h, const Op& oc, int n) {
     // round); the separate launches win once they fill the chip.
     const long long tiles = (M + 63) / 64;
     if (tiles <= h->tune.plan_cus && 2 * tiles > h->tune.plan_cus) return 64;
-    // 128-pixel tiles (bneck_xn128_f16, round 4: half the weight traffic per pixel) are NOT part of the default plan: at batch 64
-    // (613 tiles, 2.4 rounds) the launch measures 157-163 us against 162 for the two launches it replaces - with every memory
-    // stream dropped it still takes 132 us (tools/study/xn128_ablate.py): it is bound by its two barriers per 64-channel chunk,
-    // not by bytes. tune.xn_tm = 128 selects it (bit-identical, tests/test_gpu_bneck.py).
+    // (the same launch on 128-pixel tiles and as a one-barrier pipeline - round 4, five forms at 154-182 us against 159 for the two
+    // launches at batch 64 - is retired: tools/study/retired_r05_forms.patch)
     return 0;
 }
 bool xn_active(const yh_engine* h, const Op& oc, int n) { return xn_tile(h, oc, n) != 0; }
@@ -1176,7 +1157,6 @@ int fill_xn_params(yh_engine* h, const Op& oc, int n, BneckParams* out) {
     p.w1n = pa.w; p.w1n_bytes = (unsigned)((size_t)pa.coutPad * pa.Kpad * 2); p.bias1n = pa.bias;
     p.a_next = (!h->fp8_active || oa.write_f16) ? oa.out.d : nullptr;
     if (h->fp8_active && oa.write_q) { p.a_next8 = oa.out.q; p.a_next8_inv = h->inv_dev[oa.out.sid]; }
-    p.stagger = h->tune.ablate >> 4;   // timing only (bneck_xn128_f16): bits 4-7 of tune.ablate drop the residual / y-store / W_c / W_a' stream
     *out = p;
     return YH_OK;
 }
@@ -1190,7 +1170,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
         BneckParams bp;
         const int rc = fill_xn_params(h, o, n, &bp);
         if (rc) return rc;
-        e = launch_bneck(bp, 256, xn_tile(h, o, n) + (h->tune.xn_pipe ? 1000 : 0), side ? h->side : h->stream);
+        e = launch_bneck(bp, 256, xn_tile(h, o, n), side ? h->side : h->stream);
         if (e != hipSuccess) return h->fail(YH_EHIP, "bneck_chain_f16 (no 3x3):" + o.name + ": " + hipGetErrorString(e));
         return YH_OK;
     }
@@ -1212,7 +1192,7 @@ int launch_op(yh_engine* h, const Op& o, int n, bool side = false) {
             ConvTile tile;
             int rc = fill_conv_params(h, o, n, &p, &tile);
             if (rc) return rc;
-            if (side && p.partial) { p.partial = h->splitk_ws_side; if (p.tile_cnt) p.tile_cnt = h->splitk_cnt_side; }
+            if (side && p.partial) p.partial = h->splitk_ws_side;
             e = launch_conv_planned(h->tune, p, tile, h->panels[o.panel].coutPad, side ? h->side : h->stream);
             break;
         }
@@ -1333,14 +1313,14 @@ int wait_input(yh_engine* h) {
     return YH_OK;
 }
 
-// One capture (and one pinned allocation) at a time in the process. Handles of a group take their first step on threads of their own
-// (group.hip, run_members): a member capturing its step while its neighbour allocated pinned staging memory - both once-only, both
-// deep in the HIP runtime - took the process down with a host segfault in yh_evaluate once in a full test run (never alone). Steady
-// state never comes here: a captured step is replayed, staging buffers are allocated once.
-std::mutex& setup_mutex() { static std::mutex m; return m; }
-
+// Once-only work - a graph capture (hipStreamBeginCapture ... hipGraphInstantiate, and with it the first resolution of every kernel
+// of the step on this device) - happens on the thread that calls into the library, never on a group's worker thread, and a group
+// makes those calls one after the other before any worker runs (group.hip, ensure_prepared; DESIGN.md section 7 has the audit of
+// which runtime calls could otherwise overlap a capture). The two counters below are the proof the tests read
+// (yh_debug_setup_audit): a setup section that begins while a worker job is in flight anywhere in the process, or a worker job
+// that begins inside a setup section, counts as an overlap.
 int capture_step(yh_engine* h, int n, int with_tail, hipGraphExec_t* out) {
-    std::lock_guard<std::mutex> once_only(setup_mutex());
+    yh::SetupScope once_only_section;
     hipGraph_t g = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
@@ -1378,6 +1358,8 @@ int run(yh_engine* h, int with_tail) {
     const int key = (n * 2 + (with_tail ? 1 : 0)) * 2 + h->in_cur;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
+        // (a group's worker thread never captures: yh_group_* prepare every member's step shape on the caller's thread first)
+        if (h->worker_mode) return h->fail(YH_ESTATE, "internal: a group member was handed a step shape that was not prepared on the caller's thread");
         // first step of this shape: capture it for BOTH input buffers now, so that the alternation of yh_set_input_* never
         // puts a capture inside a timed region later
         const int cur = h->in_cur;
@@ -1557,7 +1539,7 @@ int ensure_out_f32(yh_engine* h, size_t nfloats) {
 // ================================================================================================
 extern "C" {
 
-const char* yh_version(void) { return "yolact-hip 0.4.0 (gfx950, MFMA f16 / fp8 implicit-GEMM; ABI 3)"; }
+const char* yh_version(void) { return "yolact-hip 0.5.0 (gfx950, MFMA f16 / fp8 implicit-GEMM; ABI 4)"; }
 
 void yh_default_config(yh_config* cfg) {
     memset(cfg, 0, sizeof *cfg);
@@ -1649,13 +1631,18 @@ int yh_create(const yh_config* cfg, yh_engine** out) {
         h->splitk_ws = (float*)q;
         if ((rc = dev_alloc(h, &q, yh_engine::kSplitKBytes))) return bail(rc);
         h->splitk_ws_side = (float*)q;
-        if ((rc = dev_alloc(h, &q, 2 * yh_engine::kSplitKTiles * sizeof(unsigned)))) return bail(rc);
-        if (hipMemset(q, 0, 2 * yh_engine::kSplitKTiles * sizeof(unsigned)) != hipSuccess) { h->err = "split-K counters: memset failed"; return bail(YH_EHIP); }
-        h->splitk_cnt = (unsigned*)q;
-        h->splitk_cnt_side = h->splitk_cnt + yh_engine::kSplitKTiles;
     }
     e = hipMemcpy(h->priors_dev, h->priors_host.data(), h->priors_host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { h->err = "priors upload failed"; return bail(YH_EHIP); }
+    // The pinned double buffer small pageable inputs are staged through (set_input): allocated HERE, with the handle - a pinned
+    // allocation takes milliseconds and used to happen at the first host input, i.e. inside whatever the caller timed after its
+    // warm-up and, for group members, on a worker thread beside a neighbour's graph capture (round 4's host segfault: DESIGN.md section 7)
+    for (int j = 0; j < 2 && e == hipSuccess; ++j) {
+        e = hipHostMalloc((void**)&h->stage[j], yh_engine::kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->stage_ev[j], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(h->stage_ev[j], h->copy);
+    }
+    if (e != hipSuccess) { h->err = std::string("pinned staging buffers: ") + hipGetErrorString(e); return bail(YH_EHIP); }
     *out = h;
     return YH_OK;
 }
@@ -1710,10 +1697,10 @@ int yh_get_tuning(const yh_engine* h, yh_tuning* out) {
     const Tune& t = h->tune;
     out->plan_cus = t.plan_cus; out->mfma16 = t.mfma16; out->t128x256_m16 = t.t128x256_m16; out->small16 = t.small16; out->bigk = t.bigk;
     out->tailsplit = t.tailsplit; out->chsplit = t.chsplit; out->k1tile = t.k1tile; out->k1_maxk = t.k1_maxk; out->splitk_minsteps = t.splitk_minsteps;
-    out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps; out->t64_s4 = t.t64_s4; out->s4 = t.s4;
+    out->t64 = t.t64; out->t64_maxb = t.t64_maxb; out->t64_minsteps = t.t64_minsteps;
     out->stemfuse = t.stemfuse; out->prefuse = t.prefuse; out->headmerge = t.headmerge; out->upfuse = t.upfuse; out->k1_generic = t.k1_generic;
     out->ablate = t.ablate; out->op_tile = t.op_tile; out->op_kslices = t.op_kslices; out->tailfork = t.tailfork; out->dsfuse = t.dsfuse; out->headfork_maxb = t.headfork_maxb; out->protofuse = t.protofuse; out->k1_min1 = t.k1_min1; out->k1_min3 = t.k1_min3; out->chain = t.chain;
-    out->xn_tm = t.xn_tm; out->tfl_fuse = 1; out->tfl_streams = 1; out->tfl_group = 1; out->xn_pipe = t.xn_pipe; out->fp8_s3 = t.fp8_s3; out->splitk_inl = t.splitk_inl; out->direct = t.direct;
+    // (tfl_dot, tfl_graph, tfl_fuse, tfl_group belong to yh_tfl handles - yh_tfl_create_tuned - and stay -1 here: an engine handle does not carry them)
     return YH_OK;
 }
 
@@ -2053,16 +2040,6 @@ static int set_input(yh_engine* h, const uint8_t* src, int n, hipMemcpyKind kind
     }
     if (kind == hipMemcpyHostToDevice && !pinned_src && bytes <= yh_engine::kStageBytes) {
         const int k = h->stage_idx ^= 1;
-        if (!h->stage[0]) {
-            std::lock_guard<std::mutex> once_only(setup_mutex());
-            // BOTH staging buffers at the first host input: allocated one call apart, the second 4 MB pinned allocation - milliseconds -
-            // fell into whatever the caller was timing after its warm-up call
-            for (int j = 0; j < 2; ++j) {
-                HIPCHK(h, hipHostMalloc((void**)&h->stage[j], yh_engine::kStageBytes, hipHostMallocDefault));
-                HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[j], hipEventDisableTiming));
-                HIPCHK(h, hipEventRecord(h->stage_ev[j], h->copy));
-            }
-        }
         HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));   // the copy that last used this staging buffer has finished
         memcpy(h->stage[k], src, bytes);
         HIPCHK(h, hipMemcpyAsync(dst, h->stage[k], bytes, hipMemcpyHostToDevice, h->copy));
@@ -2082,6 +2059,34 @@ int yh_set_input_u8_device(yh_engine* h, const uint8_t* rgb_dev, int32_t n) { re
 
 int yh_invoke(yh_engine* h) { return h ? run(h, 0) : YH_EINVAL; }
 int yh_evaluate(yh_engine* h) { return h ? run(h, 1) : YH_EINVAL; }
+
+int yh_prepare(yh_engine* h, int32_t n_frames, int32_t with_tail) {
+    if (!h) return YH_EINVAL;
+    if (n_frames < 1 || n_frames > h->cfg.max_batch) return h->fail(YH_EINVAL, "n_frames out of range");
+    if (!h->weights_loaded) return h->fail(YH_ESTATE, "weights not loaded");
+    if (h->cfg.precision == YH_PRECISION_FP8 && !h->fp8_ready) return h->fail(YH_ESTATE, "fp8 precision: set the activation scales (yh_fp8_calibrate) before preparing a step");
+    if (!h->cfg.use_graph) return YH_OK;   // eager handles have nothing to capture
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int key0 = (n_frames * 2 + (with_tail ? 1 : 0)) * 2;
+    const int cur = h->in_cur;
+    int rc = YH_OK;
+    for (int b = 0; b < 2 && rc == YH_OK; ++b) {
+        if (h->graphs.count(key0 | b)) continue;
+        h->in_cur = b;
+        hipGraphExec_t ge = nullptr;
+        rc = capture_step(h, n_frames, with_tail ? 1 : 0, &ge);
+        if (rc == YH_OK) h->graphs.emplace(key0 | b, ge);
+    }
+    h->in_cur = cur;
+    return rc;
+}
+
+int yh_debug_setup_audit(int64_t out[4]) {
+    if (!out) return YH_EINVAL;
+    yh::SetupAudit& a = yh::setup_audit();
+    out[0] = a.setups.load(); out[1] = a.worker_jobs.load(); out[2] = a.overlaps.load(); out[3] = (int64_t)a.setup_active.load() + a.worker_active.load();
+    return YH_OK;
+}
 
 int yh_sync(yh_engine* h) {
     if (!h) return YH_EINVAL;
@@ -2582,7 +2587,7 @@ int yh_profile_run(yh_engine* h, int32_t with_tail, int32_t reps, float* ms, dou
                 // expand conv + next reduce conv: both convolutions' FLOPs; HBM bytes = b + residual in, y + a' out, the weights
                 const Op& oa = h->ops[o.xn_a];
                 const double px = (double)n * o.P * o.Q;
-                h->prof_labels[i] = std::string(bneck_symbol(256, xn_tile(h, o, n) + (h->tune.xn_pipe ? 1000 : 0), true, false)) + ":" + o.name + "+" + oa.name;
+                h->prof_labels[i] = std::string(bneck_symbol(256, xn_tile(h, o, n), true, false)) + ":" + o.name + "+" + oa.name;
                 fl += oa.flops_per_img * n;
                 by = 2.0 * px * (256.0 + 1024.0 + 1024.0) + px * 256.0 * ((oa.write_f16 || !h->fp8_active ? 2.0 : 0.0) + (h->fp8_active && oa.write_q ? 1.0 : 0.0)) + o.bytes_fixed + oa.bytes_fixed;
             } else if (o.kind == OP_CONV && chain_active(h, o, n)) {
@@ -2688,7 +2693,6 @@ static int op_conv2d_impl(yh_engine* h, const uint16_t* x, int32_t n, int32_t hh
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = coutPad;
             p.partial = h->splitk_ws;
-            if (h->tune.splitk_inl && (long long)((p.M + conv_tile_m(tile) - 1) / conv_tile_m(tile)) * p.n_ch_tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
         e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -2755,7 +2759,6 @@ int yh_op_conv2d_dual_f16(yh_engine* h, const uint16_t* x1, int32_t n, int32_t h
             p.k_slices = (p.ksteps + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
             p.partial_ld = coutPad;
             p.partial = h->splitk_ws;
-            if (h->tune.splitk_inl && (long long)((p.M + conv_tile_m(tile) - 1) / conv_tile_m(tile)) * p.n_ch_tiles <= yh_engine::kSplitKTiles) p.tile_cnt = h->splitk_cnt;
         }
         e = launch_conv_planned(h->tune, p, tile, coutPad, h->stream, &h->last_conv_launches);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -82,6 +82,7 @@ struct yh_group {
     std::vector<int> dev;
     std::vector<Worker*> workers;
     std::vector<int> start, count;   // the partition of the last evaluate: member i owns frames [start[i], start[i] + count[i])
+    std::vector<char> warm;          // member i has taken a step before (eager members take their FIRST one on the caller's thread)
     int max_batch = 0, total = 0;
     size_t frame_bytes = 0;
     std::string err, replication = "no weights loaded";
@@ -127,6 +128,7 @@ int yh_group_create(const yh_config* cfg, const int32_t* devices, int32_t n, yh_
     for (int i = 0; i < n; ++i) { g->workers.push_back(new Worker()); g->workers.back()->start(); }
     g->start.assign(n, 0);
     g->count.assign(n, 0);
+    g->warm.assign(n, 0);
     *out = g;
     return YH_OK;
 }
@@ -228,17 +230,79 @@ static void partition(yh_group* g, int n_frames) {
     g->total = n_frames;
 }
 
-static int run_members(yh_group* g, const std::function<int(int)>& job) {
+// Once-only work happens HERE, on the caller's thread, one member after the other, while every worker is idle (run_members has
+// returned: a worker only ever runs inside it). What that is: the graph capture of a step shape a member has not run yet
+// (hipStreamBeginCapture ... hipGraphInstantiate for both of its input buffers, and with it the first resolution of the step's
+// kernels on that device). A shape that appears later (another block size) is captured the same way after the members' streams
+// have drained. Members that run eagerly (use_graph = 0) have nothing to capture; they take their first step on this thread
+// instead (run_members). The worker threads therefore only ever issue steady-state calls - hipSetDevice, event record / wait,
+// hipMemcpyAsync, hipGraphLaunch (eager members: kernel launches) - and engine.hip refuses a capture in worker mode. Round 4's
+// host segfault (a member capturing beside a neighbour's first pinned allocation, both on worker threads) has no place left to
+// happen; its cause inside the runtime stays unproven.
+static int ensure_prepared(yh_group* g, int with_tail) {
     const int m = (int)g->eng.size();
-    for (int i = 0; i < m; ++i)
-        if (g->count[i] > 0) g->workers[i]->post([i, &job] { return job(i); });
-    int first = YH_OK, who = -1;
+    bool drained = false;
     for (int i = 0; i < m; ++i) {
-        if (g->count[i] <= 0) continue;
+        if (g->count[i] <= 0 || yh::engine_step_prepared(g->eng[i], g->count[i], with_tail)) continue;
+        if (!drained) {   // a capture that is needed later than the first step: the group drains first
+            for (int k = 0; k < m; ++k) { const int rc = yh_sync(g->eng[k]); if (rc) return g->member_fail(k, rc); }
+            drained = true;
+        }
+        const int rc = yh_prepare(g->eng[i], g->count[i], with_tail);
+        if (rc) return g->member_fail(i, rc);
+    }
+    return YH_OK;
+}
+
+static int run_members(yh_group* g, int with_tail, const std::function<int(int)>& job) {
+    const int m = (int)g->eng.size();
+    int rc0 = ensure_prepared(g, with_tail);
+    if (rc0) return rc0;
+    std::vector<char> posted((size_t)m, 0);
+    int first = YH_OK, who = -1;
+    for (int i = 0; i < m; ++i) {   // a member's first step ever, if it runs eagerly: on this thread, before any worker starts
+        if (g->count[i] <= 0 || g->warm[i]) continue;
+        g->warm[i] = 1;
+        if (yh::engine_uses_graph(g->eng[i])) continue;
+        const int rc = job(i);
+        posted[i] = 2;
+        if (rc && !first) { first = rc; who = i; }
+    }
+    for (int i = 0; i < m; ++i)
+        if (g->count[i] > 0 && !posted[i]) {
+            posted[i] = 1;
+            yh_engine* e = g->eng[i];
+            g->workers[i]->post([i, e, &job] {
+                yh::WorkerScope in_flight;
+                yh::engine_set_worker_mode(e, true);
+                const int rc = job(i);
+                yh::engine_set_worker_mode(e, false);
+                return rc;
+            });
+        }
+    for (int i = 0; i < m; ++i) {
+        if (posted[i] != 1) continue;
         const int rc = g->workers[i]->wait();
         if (rc && !first) { first = rc; who = i; }
     }
     return first ? g->member_fail(who, first) : YH_OK;
+}
+
+// Captures, on the calling thread and one member at a time, the step every member would run for a call with n_frames frames
+// (both input buffers of each block size): what yh_group_evaluate would otherwise do at the first call of that size. A host
+// calls it for its block sizes at start-up so that no capture falls into its frame loop. Requires the weights (and, in fp8
+// precision, the scales).
+int yh_group_prepare(yh_group* g, int32_t n_frames, int32_t with_tail) {
+    DeviceGuard restore_callers_device;
+    if (!g) return YH_EINVAL;
+    const int m = (int)g->eng.size();
+    if (n_frames < 1 || (long long)n_frames > (long long)m * g->max_batch) return g->fail(YH_EINVAL, "n_frames must be 1 .. members * max_batch");
+    const std::vector<int> s0 = g->start, c0 = g->count;
+    const int t0 = g->total;
+    partition(g, n_frames);
+    const int rc = ensure_prepared(g, with_tail);
+    g->start = s0; g->count = c0; g->total = t0;   // (the results of the last evaluate stay addressable)
+    return rc;
 }
 
 // n_frames u8 RGB frames [n][S][S][3] in HOST memory: member i takes its contiguous block (yh_set_input_u8: the copy runs on
@@ -251,7 +315,7 @@ int yh_group_evaluate(yh_group* g, const uint8_t* frames_host, int32_t n_frames,
     if (n_frames < 1 || (long long)n_frames > (long long)m * g->max_batch) return g->fail(YH_EINVAL, "n_frames must be 1 .. members * max_batch");
     yh::TraceRange tr("yh_group_evaluate");
     partition(g, n_frames);
-    return run_members(g, [&](int i) {
+    return run_members(g, with_tail, [&](int i) {
         int rc = yh_set_input_u8(g->eng[i], frames_host + (size_t)g->start[i] * g->frame_bytes, g->count[i]);
         if (rc == YH_OK) rc = with_tail ? yh_evaluate(g->eng[i]) : yh_invoke(g->eng[i]);
         return rc;
@@ -274,7 +338,7 @@ int yh_group_evaluate_device(yh_group* g, const uint8_t* const* frames_dev, cons
     if (total < 1) return g->fail(YH_EINVAL, "no frames");
     g->total = total;
     yh::TraceRange tr("yh_group_evaluate_device");
-    return run_members(g, [&](int i) {
+    return run_members(g, with_tail, [&](int i) {
         int rc = yh_set_input_u8_device(g->eng[i], frames_dev[i], g->count[i]);
         if (rc == YH_OK) rc = with_tail ? yh_evaluate(g->eng[i]) : yh_invoke(g->eng[i]);
         return rc;

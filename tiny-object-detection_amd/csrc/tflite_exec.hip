@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void tfl_conv_i8_mfma(const ConvI8 p) {
 // without) - on 2 to 50 workgroups of a 256-CU chip. Here a lane finishes 4 outputs, a 7-workgroup layer becomes 100 waves, a k-step
 // is 2 loads, 4 v_dot4, 4 v_xor and 1 MFMA, and D steps of loads are in flight (a ring of registers indexed at compile time). The
 // re-reads of the operands (each weight row by every pixel tile, each pixel by every channel tile) are L2 hits. K chunks past Ci
-// (Ci % 16 == 0, not % 64: 16, 32, 96, 144 channels) are fed zeros on both sides, which add nothing to sum x'w' nor to sum x.
+// (Ci % 4 == 0, not % 64: 16, 24, 32, 96, 144 channels) are fed zeros on both sides, which add nothing to sum x'w' nor to sum x.
 // D = the depth of the register ring = the k-steps of one loop iteration. The loop body has NO branch: with a wave-uniform
 // `if (step < nsteps)` around each step hipcc's wait insertion gave up counting and put s_waitcnt vmcnt(0..3) in front of every step
 // - eight steps of loads "in flight" that were waited for one by one. So the k-steps are rounded up to a multiple of D (the launch
@@ -749,9 +749,6 @@ struct Prepared {
     PKind kind;
     int oi = -1;         // operator index in the model
     bool dead = false;   // folded into another launch (fuse_plan)
-    int lane = 0;        // stream it is launched on (schedule_plan); 0 = the handle's own stream
-    std::vector<int> waits;   // plan entries on OTHER lanes whose completion it waits for (their events)
-    bool signal = false;      // an entry on another lane waits for it: record its event behind the launch
     int group = -1;           // >= 0: this convolution is launched as part of h->groups[group] (group_plan), by the group's first member
     ConvQ conv; ConvI8 ci8; AddQ add; PadQ pad; ResizeQ rs;
     std::vector<CatQ> cat;
@@ -776,16 +773,6 @@ struct yh_tfl {
     int nb = 1;                                  // images of the next invoke (yh_tfl_set_batch)
     bool batch_ok = true;                        // no operator of the model touches the image axis
     hipGraphExec_t gexecs[kMaxBatch] = { nullptr, nullptr };   // the plan per batch size, captured once and replayed (tensor addresses never change)
-    // yh_tuning.tfl_streams (round 4): the plan is a DAG - five pyramid levels with four head convolutions each, the protonet beside
-    // them - and its launches are 2-200 workgroups on 256 CUs: independent launches run SIDE BY SIDE on up to four streams
-    // (schedule_plan), forked from and joined into the handle's stream inside every invoke. Measured interleaved in one process
-    // (tools/time_tflite_fuse.py, 136-op model): 1 lane 0.920 ms per invoke, 2 lanes 0.920, 4 lanes 0.927, 6 lanes 0.902 - the
-    // backbone is a chain and the event edges cost what the overlap of the heads gains, so the default stays ONE lane.
-    int n_lanes = 1;
-    std::vector<hipStream_t> lanes;   // [0] = stream
-    std::vector<hipEvent_t> pev;      // per plan entry (created for the signalling ones)
-    hipEvent_t ev_start = nullptr;
-    std::vector<hipEvent_t> ev_end;   // per side lane
     // yh_tuning.tfl_group (round 4): independent register-fed convolutions of one kernel form and one depth of the plan's DAG as ONE
     // launch (group_plan); `order` is the plan in execution order (by depth; the identity when nothing is grouped)
     struct ConvGroup { std::vector<int> members; const ConvI8* probs[kMaxBatch] = { nullptr, nullptr }; const int* tile_start[kMaxBatch] = { nullptr, nullptr }; int tiles[kMaxBatch] = { 0, 0 }; };
@@ -794,7 +781,7 @@ struct yh_tfl {
     std::vector<int> order;
     int use_fuse = 1;                 // yh_tuning.tfl_fuse: element-wise operators / PAD / CONCATENATION parts folded into their producers (fuse_plan)
     std::vector<char> gone;           // tensor i is never written by the fused plan (yh_tfl_tensor_read says so)
-    int use_dot = 3, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel on LDS tiles where Ci % 64 == 0, 3 + its register-fed form where Ci % 16 == 0: default) / tfl_graph
+    int use_dot = 3, use_graph = 0;   // yh_tuning.tfl_dot (0 scalar kernel, 1 v_dot4 kernel, 2 + int8 MFMA kernel on LDS tiles where Ci % 64 == 0, 3 + its register-fed form - one wave per 16 x 16 tile - where Ci % 4 == 0: default) / tfl_graph
     hipStream_t side = nullptr;       // tfl_graph: carries the second branch of the captured graph
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* side_word = nullptr;
@@ -1249,80 +1236,8 @@ int group_plan(yh_tfl* h) {
 }
 
 
-// Static list scheduling of the (fused) plan onto the lanes. What an entry reads and writes is taken from its final device pointers
-// (after fusion an output may live inside a CONCATENATION's buffer), resolved to the allocation that holds them; an entry depends on
-// every earlier entry that wrote an allocation it reads (tensors are written once per invoke; the parts of a concatenation are
-// disjoint). An entry continues the lane of a producer that is that lane's last entry, else takes the lane with the least
-// estimated work; a dependency on another lane becomes an event wait.
-int schedule_plan(yh_tfl* h) {
-    struct Range { const char* lo; const char* hi; };
-    std::vector<Range> al;
-    for (size_t i = 0; i < h->tens.size(); ++i)
-        if (h->tens[i] && !h->alias[i]) {
-            const TflTensor& t = h->m.tensors[i];
-            const size_t bytes = t.count() * t.elem();
-            al.push_back(Range{ (const char*)h->tens[i], (const char*)h->tens[i] + (t.data ? bytes : bytes * yh_tfl::kMaxBatch) + 16 });
-        }
-    auto alloc_of = [&](const void* q) -> int {
-        for (size_t i = 0; i < al.size(); ++i) if ((const char*)q >= al[i].lo && (const char*)q < al[i].hi) return (int)i;
-        return -1;
-    };
-    const int np = (int)h->plan.size();
-    std::vector<std::vector<int>> writers(al.size());
-    std::vector<double> lane_work((size_t)h->n_lanes, 0.0);
-    std::vector<int> lane_last((size_t)h->n_lanes, -1);
-    for (int i = 0; i < np; ++i) {
-        Prepared& p = h->plan[i];
-        if (p.dead) continue;
-        std::vector<const void*> rd, wr;
-        double cost = 5.0;   // us: a small launch
-        switch (p.kind) {
-            case P_CONV: case P_DW: rd.push_back(p.conv.x); wr.push_back(p.conv.y); if (p.conv.po.other) rd.push_back(p.conv.po.other); cost = 8.0; break;
-            case P_CONV_I8: rd.push_back(p.ci8.x); wr.push_back(p.ci8.y); if (p.ci8.po.other) rd.push_back(p.ci8.po.other);
-                            cost = 6.4 + 0.36 * (p.ci8.kh * p.ci8.kw * (p.ci8.Ci >> 6)); break;   // (tools/study/tfl_conv_steps.py)
-            case P_ADD: rd.push_back(p.add.a); rd.push_back(p.add.b); wr.push_back(p.add.y); break;
-            case P_PAD: rd.push_back(p.pad.x); wr.push_back(p.pad.y); break;
-            case P_RESIZE: rd.push_back(p.rs.x); wr.push_back(p.rs.y); if (p.rs.po.other) rd.push_back(p.rs.po.other); break;
-            case P_CONCAT: for (const CatQ& c : p.cat) { rd.push_back(c.x); wr.push_back(c.y); } cost = 5.0 * (double)p.cat.size(); break;
-            default: rd.push_back(p.src); wr.push_back(p.dst); break;
-        }
-        std::vector<int> deps;
-        for (const void* q : rd) {
-            const int a = alloc_of(q);
-            if (a < 0) continue;
-            for (int w : writers[a]) if (w < i && std::find(deps.begin(), deps.end(), w) == deps.end()) deps.push_back(w);
-        }
-        int lane = -1;
-        for (int d : deps) {   // continue a producer's lane where this entry can follow it directly (lowest lane first)
-            const int l = h->plan[d].lane;
-            if (lane_last[l] == d && (lane < 0 || l < lane)) lane = l;
-        }
-        if (lane < 0) {
-            lane = 0;
-            for (int l = 1; l < h->n_lanes; ++l) if (lane_work[l] < lane_work[lane]) lane = l;
-        }
-        p.lane = lane;
-        p.waits.clear();
-        for (int d : deps)
-            if (h->plan[d].lane != lane) { p.waits.push_back(d); h->plan[d].signal = true; }
-        lane_work[lane] += cost;
-        // (a lane runs in order: it cannot start this entry before its own tail; waiting moves the lane's clock to the producers' finish)
-        lane_last[lane] = i;
-        for (const void* q : wr) { const int a = alloc_of(q); if (a >= 0) writers[a].push_back(i); }
-    }
-    h->pev.assign((size_t)np, nullptr);
-    for (int i = 0; i < np; ++i)
-        if (h->plan[i].signal) TCHK(h, hipEventCreateWithFlags(&h->pev[i], hipEventDisableTiming));
-    return YH_OK;
-}
-
 int enqueue_plan(yh_tfl* h) {
-    const bool multi = h->n_lanes > 1;
-    hipStream_t s = h->stream;
-    if (multi) {   // fork: the side lanes start behind everything the handle's stream has been given (the input copy, the previous invoke's join)
-        TCHK(h, hipEventRecord(h->ev_start, h->stream));
-        for (int l = 1; l < h->n_lanes; ++l) TCHK(h, hipStreamWaitEvent(h->lanes[l], h->ev_start, 0));
-    }
+    const hipStream_t s = h->stream;
     const unsigned nb = (unsigned)h->nb;   // images of this invoke: activations are image-major, so element-wise ops just see nb x the elements
     TraceRange tr_all("yh_tfl:plan(enqueue)");
     for (size_t oi = 0; oi < h->order.size(); ++oi) {
@@ -1330,10 +1245,6 @@ int enqueue_plan(yh_tfl* h) {
         const Prepared& p = h->plan[pi];
         if (p.dead) continue;   // folded into another launch (fuse_plan)
         if (p.group >= 0 && h->groups[p.group].members[0] != (int)pi) continue;   // launched with its group's first member
-        if (multi) {
-            s = h->lanes[p.lane];
-            for (int d : p.waits) TCHK(h, hipStreamWaitEvent(s, h->pev[d], 0));
-        }
         static const char* kind_name[] = { "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RELU/QUANTIZE", "QUANTIZE(f32)", "DEQUANTIZE", "TANH", "PAD", "RESIZE_BILINEAR", "CONCATENATION", "RESHAPE(copy)", "CONV_2D(int8 MFMA)" };
         TraceRange tr(kind_name[p.kind]);   // (roctx: one range per operator, named by its TFLite op; a no-op unless a tracer is attached)
         switch (p.kind) {
@@ -1374,13 +1285,6 @@ int enqueue_plan(yh_tfl* h) {
             case P_RESIZE: hipLaunchKernelGGL(tfl_resize_bilinear_u8, dim3(nblk((long long)p.rs.Ho * p.rs.Wo * p.rs.C), nb), dim3(256), 0, s, p.rs); break;
             case P_CONCAT: for (CatQ c : p.cat) { c.outer *= nb; hipLaunchKernelGGL(tfl_concat_part, dim3(nblk(c.outer * c.inner * c.esz)), dim3(256), 0, s, c); } break;
             case P_COPY: hipLaunchKernelGGL(tfl_copy_bytes, dim3(nblk(((p.n * nb) >> 4) + 16)), dim3(256), 0, s, (const uint8_t*)p.src, (uint8_t*)p.dst, p.n * nb); break;
-        }
-        if (multi && p.signal) TCHK(h, hipEventRecord(h->pev[pi], s));
-    }
-    if (multi) {   // join: the handle's stream continues behind every lane
-        for (int l = 1; l < h->n_lanes; ++l) {
-            TCHK(h, hipEventRecord(h->ev_end[l], h->lanes[l]));
-            TCHK(h, hipStreamWaitEvent(h->stream, h->ev_end[l], 0));
         }
     }
     hipError_t e = hipGetLastError();
@@ -1471,11 +1375,6 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     if (tune && tune->tfl_graph >= 0) h->use_graph = tune->tfl_graph;
     if (tune && tune->tfl_fuse >= 0) h->use_fuse = tune->tfl_fuse;
     if (tune && tune->tfl_group >= 0) h->use_group = tune->tfl_group;
-    if (tune && tune->tfl_streams >= 1) h->n_lanes = tune->tfl_streams > 8 ? 8 : tune->tfl_streams;
-    // The captured form keeps one lane: capturing the 4-lane plan (some 80 cross-stream event edges) took the process down
-    // inside the HIP runtime on ROCm 7.2 (a host segfault in the invoke that captures), and the graph form is the slower,
-    // opt-in one anyway (see run_plan).
-    if (h->use_graph) h->n_lanes = 1;
     h->file.assign((const uint8_t*)model_bytes, (const uint8_t*)model_bytes + nbytes);
     auto bail = [&](int rc) { g_tfl_create_error = h->err; yh_tfl_destroy(h); return rc; };
     if (!h->m.parse(h->file.data(), h->file.size())) { h->err = "tflite parse: " + h->m.error; return bail(YH_EWEIGHTS); }
@@ -1488,16 +1387,7 @@ int yh_tfl_create_tuned(const void* model_bytes, size_t nbytes, int32_t device, 
     h->gone.assign(h->m.tensors.size(), 0);
     if (h->use_fuse) fuse_plan(h);
     for (int i = 0; i < (int)h->plan.size(); ++i) h->order.push_back(i);
-    if (h->use_group && h->n_lanes == 1 && (rc = group_plan(h))) return bail(rc);
-    h->lanes.assign(1, h->stream);
-    h->ev_end.assign((size_t)h->n_lanes, nullptr);
-    for (int l = 1; l < h->n_lanes; ++l) {
-        hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_end[l], hipEventDisableTiming) != hipSuccess) { h->err = "lane setup failed"; return bail(YH_EHIP); }
-        h->lanes.push_back(st);
-    }
-    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) { h->err = "lane setup failed"; return bail(YH_EHIP); }
-    if (h->n_lanes > 1 && (rc = schedule_plan(h))) return bail(rc);
+    if (h->use_group && (rc = group_plan(h))) return bail(rc);
     *out = h;
     return YH_OK;
 }
@@ -1526,10 +1416,6 @@ void yh_tfl_destroy(yh_tfl* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (hipGraphExec_t ge : h->gexecs) if (ge) hipGraphExecDestroy(ge);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
-    for (size_t l = 1; l < h->lanes.size(); ++l) { hipStreamSynchronize(h->lanes[l]); hipStreamDestroy(h->lanes[l]); }
-    for (hipEvent_t e : h->pev) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_end) if (e) hipEventDestroy(e);
-    if (h->ev_start) hipEventDestroy(h->ev_start);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->side_word) hipFree(h->side_word);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,31 @@ struct TraceRange {
     TraceRange(const TraceRange&) = delete;
     TraceRange& operator=(const TraceRange&) = delete;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Setup audit (engine.hip): once-only work - graph captures - is done on the calling thread, and a group
+// does it for all its members one after the other BEFORE its worker threads run. SetupScope brackets such a section, WorkerScope
+// a worker thread's job; an overlap of the two anywhere in the process is counted and yh_debug_setup_audit reports it (the
+// tests assert 0). Counters only: nothing waits on them.
+// ---------------------------------------------------------------------------------------------
+struct SetupAudit { std::atomic<int> setup_active{0}, worker_active{0}; std::atomic<long long> setups{0}, worker_jobs{0}, overlaps{0}; };
+SetupAudit& setup_audit();   // engine.hip
+struct SetupScope {
+    SetupScope() { SetupAudit& a = setup_audit(); a.setups++; a.setup_active++; if (a.worker_active.load() > 0) a.overlaps++; }
+    ~SetupScope() { SetupAudit& a = setup_audit(); if (a.worker_active.load() > 0) a.overlaps++; a.setup_active--; }
+    SetupScope(const SetupScope&) = delete;
+    SetupScope& operator=(const SetupScope&) = delete;
+};
+struct WorkerScope {
+    WorkerScope() { SetupAudit& a = setup_audit(); a.worker_jobs++; a.worker_active++; if (a.setup_active.load() > 0) a.overlaps++; }
+    ~WorkerScope() { setup_audit().worker_active--; }
+    WorkerScope(const WorkerScope&) = delete;
+    WorkerScope& operator=(const WorkerScope&) = delete;
+};
+// group.hip drives its members through these (not part of the C ABI)
+void engine_set_worker_mode(yh_engine* h, bool on);
+bool engine_step_prepared(const yh_engine* h, int n_frames, int with_tail);   // eager handles: always true
+bool engine_uses_graph(const yh_engine* h);
 
 // ---------------------------------------------------------------------------------------------
 // Convolution as implicit GEMM (conv_igemm.hip).
@@ -93,21 +119,17 @@ struct ConvParams {
     int ksteps_per_slice;
     int partial_ld;       // row stride of the partial slabs in floats (coutPad)
     float* partial;       // [k_slices][M][partial_ld] f32 workspace
-    unsigned* tile_cnt;   // split-K: one arrival counter per output tile (zero between launches). Set: the workgroup whose slice arrives
-                          // last sums the tile's slabs and runs the epilogue inside the launch; nullptr: splitk_reduce_f16 does, as a launch
 };
 
-// (ids 4 and 9-11 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel - DESIGN.md §4)
+// (ids 4, 9-11, 14, 17, 25, 26 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel, rings of
+// four, the fp8 ring of three, register-fed 32 x 32 tiles - DESIGN.md §4, §12; tools/study/retired_r05_forms.patch)
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8,
-                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x128_S4 = 14, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_64x64_S4 = 17, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24, TILE_128x128_FP8_S3 = 25,
-                TILE_DIRECT32 = 26 /* conv_direct.hip: 32 x 32 tiles fed from registers, K split over the workgroup's four waves */ };
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24 };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
 hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream);
 hipError_t launch_splitk_reduce(const ConvParams& p, hipStream_t stream);
-bool conv_direct_ok(const ConvParams& p);                              // conv_direct.hip: TILE_DIRECT32 can run this convolution
-hipError_t launch_conv_direct(const ConvParams& p, hipStream_t stream);
 
 // A bottleneck block's 3x3 conv, its 1x1 expand conv with the residual add, and the NEXT block's 1x1 reduce conv as one
 // kernel (bneck.hip): b stays in LDS, y and a' are written once. planes in {64, 128}.
@@ -140,8 +162,6 @@ struct BneckParams {
     unsigned res_bytes;     // ... its residual rows travel by LDS-DMA: the buffer-descriptor range of res
     uint8_t* a_next8;
     const float* a_next8_inv;   // [planes] reciprocal scales, one per channel of a'
-    int grid_cap;           // > 0: persistent grid of at most this many workgroups (each walks its tiles); 0: one workgroup per tile
-    int stagger;            // > 0: the second-dispatched half of the grid starts this many 64-clock sleep units late (phase offset)
 };
 hipError_t launch_bneck(const BneckParams& p, int planes, int tm, hipStream_t stream);
 const char* bneck_symbol(int planes, int tm, bool next, bool dual = false);

@@ -96,7 +96,14 @@ YolactGroup YolactGroup::init(const GroupOptions& opt) {
     std::int32_t pd[2] = {0, 0};
     yh_proto_dims(m0, pd);
     y.hp_ = pd[0]; y.wp_ = pd[1];
+    // allocate_tensors() (yolact.rs:35) for the full-capacity call: every member's step is captured now, on this thread, one member
+    // after the other - no capture is left for the frame loop (fp8 precision: after the calibration instead, see prepare())
+    if (opt.precision == YH_PRECISION_F16) y.prepare(y.capacity());
     return y;
+}
+
+void YolactGroup::prepare(int n_frames) {
+    if (yh_group_prepare(g_, n_frames, 1) != YH_OK) expect_failed("failed to allocate tensors.", yh_group_last_error(g_));   // yolact.rs:35
 }
 
 YolactGroup::YolactGroup(YolactGroup&& o) noexcept : g_(o.g_), opt_(std::move(o.opt_)), hp_(o.hp_), wp_(o.wp_), max_dets_(o.max_dets_) { o.g_ = nullptr; }

@@ -83,6 +83,8 @@ public:
     int members() const;
     int capacity() const { return members() * opt_.frames_per_member; }   // frames per evaluate
     std::string weights_replication() const;
+    // captures every member's step for calls with n frames (init() does it for capacity()); serial, on the calling thread
+    void prepare(int n_frames);
     // n frames of u8 RGB [n][S][S][3]: enqueues them on the members and returns (the GPUs run on; the frames are free again)
     void evaluate(const std::uint8_t* frames, int n);
     // waits for the member that holds `frame` of the last evaluate and returns its detections

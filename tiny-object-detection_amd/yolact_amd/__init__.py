@@ -10,6 +10,6 @@ Python caller uses, and `Yolact` mirrors the reference's public items one for on
 There is no CPU fallback: importing works anywhere, but creating an engine without the built
 library or without a GPU raises.
 """
-from .capi import (Engine, Group, TfliteEngine, Scene, Tuning, rccl_unique_id, group_broadcast_weights, PRECISION_F16, PRECISION_FP8, tfl_validate, YhError, Config, Detection, lib_path, load_library, version,  # noqa: F401
+from .capi import (Engine, Group, TfliteEngine, Scene, Tuning, rccl_unique_id, setup_audit, group_broadcast_weights, PRECISION_F16, PRECISION_FP8, tfl_validate, YhError, Config, Detection, lib_path, load_library, version,  # noqa: F401
                    COMPAT_STRICT, COMPAT_SANE, EDIVERGE)
 from .yolact import Yolact  # noqa: F401

@@ -21,8 +21,8 @@ PRECISION_F16, PRECISION_FP8 = 0, 1
 
 # yh_tuning (include/yolact_hip.h): per-handle measurement / test knobs, -1 = the library's default
 TUNING_FIELDS = ("plan_cus", "mfma16", "t128x256_m16", "small16", "bigk", "tailsplit", "chsplit", "k1tile", "k1_maxk",
-                 "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "t64_s4", "s4", "stemfuse", "prefuse", "headmerge",
-                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "xn_tm", "xn_pipe", "fp8_s3", "tfl_fuse", "tfl_streams", "splitk_inl", "direct", "tfl_group")
+                 "splitk_minsteps", "t64", "t64_maxb", "t64_minsteps", "stemfuse", "prefuse", "headmerge",
+                 "upfuse", "k1_generic", "ablate", "op_tile", "op_kslices", "tfl_dot", "tfl_graph", "tailfork", "dsfuse", "headfork_maxb", "protofuse", "k1_min1", "k1_min3", "chain", "tfl_fuse", "tfl_group")
 
 
 class Tuning(C.Structure):
@@ -98,6 +98,7 @@ SYMBOLS = [
     ("yh_group_fp8_calibrate", _i, [_vp]),
     ("yh_group_evaluate", _i, [_vp, _vp, _i, _i]),
     ("yh_group_evaluate_device", _i, [_vp, C.POINTER(_vp), C.POINTER(_i), _i]),
+    ("yh_group_prepare", _i, [_vp, _i, _i]),
     ("yh_group_sync", _i, [_vp]),
     ("yh_group_read_detections", _i, [_vp, _i, C.POINTER(_i), _vp, _i, _vp, _sz]),
     ("yh_group_frame_owner", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
@@ -105,6 +106,7 @@ SYMBOLS = [
     ("yh_set_input_u8", _i, [_vp, _vp, _i]),
     ("yh_set_input_u8_device", _i, [_vp, _vp, _i]),
     ("yh_invoke", _i, [_vp]),
+    ("yh_prepare", _i, [_vp, _i, _i]),
     ("yh_sync", _i, [_vp]),
     ("yh_output_count", _i, [_vp]),
     ("yh_output_info", _i, [_vp, _i, C.POINTER(TensorInfo)]),
@@ -150,6 +152,7 @@ SYMBOLS = [
     ("yh_debug_read_tensor_frame", _i, [_vp, C.c_char_p, _i, _vp, _sz, C.POINTER(_i * 4)]),
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_debug_alloc_map", _i, [_vp, C.c_char_p, _sz]),
+    ("yh_debug_setup_audit", _i, [C.POINTER(C.c_int64 * 4)]),
     ("yh_debug_graph_nodes", _i, [_vp, _i, C.c_char_p, _sz]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -183,6 +186,17 @@ def load_library():
 
 def version():
     return load_library().yh_version().decode()
+
+
+def setup_audit():
+    """yh_debug_setup_audit: process-wide counters of the setup discipline -
+    dict(setups, worker_jobs, overlaps, in_flight); `overlaps` must stay 0."""
+    L = load_library()
+    a = (C.c_int64 * 4)()
+    rc = L.yh_debug_setup_audit(C.byref(a))
+    if rc != OK:
+        raise YhError(rc, "yh_debug_setup_audit")
+    return dict(setups=a[0], worker_jobs=a[1], overlaps=a[2], in_flight=a[3])
 
 
 def rccl_unique_id():
@@ -359,6 +373,10 @@ class Engine:
 
     def evaluate(self):
         self._chk(self.L.yh_evaluate(self.h))
+
+    def prepare(self, n, with_tail=True):
+        """yh_prepare: capture the step for n frames now, on this thread (allocate_tensors() at its proper time)."""
+        self._chk(self.L.yh_prepare(self.h, n, 1 if with_tail else 0))
 
     def sync(self):
         self._chk(self.L.yh_sync(self.h))
@@ -644,6 +662,10 @@ class Group:
         assert frames.shape == (n, self.S, self.S, 3), frames.shape
         self._chk(self.L.yh_group_evaluate(self.g, _p(frames), n, 1 if with_tail else 0))
         self.total = n
+
+    def prepare(self, n_frames, with_tail=True):
+        """yh_group_prepare: capture every member's step for a call with n_frames frames, serially on this thread."""
+        self._chk(self.L.yh_group_prepare(self.g, n_frames, 1 if with_tail else 0))
 
     def evaluate_device(self, dev_ptrs, counts, with_tail=True):
         ptrs = (C.c_void_p * self.n)(*[C.c_void_p(p) for p in dev_ptrs])

@@ -4,7 +4,7 @@
 #   PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) -> traffic JSON, SQ counters of the conv kernels.
 # Usage (inside gpurun): bash tools/collect_profiles.sh r01     -> writes gpurun_out/profiles_r01/
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -35,7 +35,7 @@ python3 $R/bench.py --backbone 101 --size 700 --precision fp8 --batch 8 --no-bat
 { python3 $R/tools/time_steps.py 1 2 4 8 16 32 64; python3 $R/tools/time_classify.py; python3 $R/tools/time_tflite.py; python3 $R/tools/time_scene.py; python3 $R/tools/time_h2d.py; } > $OUT/${TAG}_timings.txt 2>&1
 python3 $R/tools/ab_chain.py 64 0 1 65 > $OUT/${TAG}_ab_chain.txt 2>&1
 # round 4: the .tflite executor under the profiler (fused plan and one launch per operator), its fused / unfused / graph timings,
-# the cost model of one int8-MFMA conv launch; layer 3's expand + next-reduce launch in all five forms, and the ablation of the pipelined one
+# the cost model of one int8-MFMA conv launch
 for f in 1 0; do
   rocprofv3 --kernel-trace --stats -d $OUT/tfl$f -o run --output-format csv -- python3 $R/tools/time_tflite_fuse.py fuse=$f,graph=0,group=$f > $OUT/tfl$f.log 2>&1
 done
@@ -49,11 +49,6 @@ for dot in 3 2; do
   rocprofv3 --kernel-trace -d $OUT/tl$dot -o run --output-format csv -- python3 $R/tools/study/tfl_layer_run.py tfl_dot=$dot,tfl_group=$((dot == 3)) > $OUT/tl$dot.log 2>&1
   python3 $R/tools/study/tfl_layer_table.py "$(find $OUT/tl$dot -name "*kernel_trace.csv" | sort | tail -1)" "$(grep LAUNCHES $OUT/tl$dot.log | cut -d' ' -f2)" > $OUT/${TAG}_tflite_layer_table_dot$dot.txt 2>&1 || true
 done
-# ... and the two batch-1 experiments that stayed opt-in: split-K finished inside the launch, the register-fed f16 convolution
-{ python3 $R/tools/ab_tune.py 1 - splitk_inl=1 direct=192; python3 $R/tools/ab_tune.py 4 - splitk_inl=1 direct=192; python3 $R/tools/study/direct_profile.py 1; } > $OUT/${TAG}_batch1_experiments.txt 2>&1
-{ python3 $R/tools/study/xn_forms.py 64; python3 $R/tools/study/xn_forms.py 8 700 101 fp8; } > $OUT/${TAG}_xn_forms.txt 2>&1
-{ python3 $R/tools/study/xn2_ablate.py 64 128; python3 $R/tools/study/xn128_ablate.py 64; } > $OUT/${TAG}_xn_ablation.txt 2>&1
-python3 $R/tools/ab_tune_c4.py 8 - fp8_s3=1 > $OUT/${TAG}_ab_fp8_ring3_configs4.txt 2>&1
 for m in "" "--fp8-per-tensor"; do python3 $R/bench.py --no-batch1 --no-tflite --cpu-budget 2 --steps 5 $m > $OUT/${TAG}_bench_fp8_scales${m}.json 2>> $OUT/bench_fp8.err; done
 python3 $R/tools/fault_audit.py > $OUT/${TAG}_fault_audit_dump.txt 2>&1
 python3 $R/bench.py --gpus 2 --single-process --batch 32 --steps 10 --warmup 3 > $OUT/${TAG}_bench_single_process_2members.json 2> $OUT/bench_sp.err

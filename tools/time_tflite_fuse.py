@@ -13,10 +13,10 @@ buf = bytes(B.serialize(model))
 x = rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)
 frame = (rng.integers(0, 256, (480, 640, 3), dtype=np.uint32) * np.array([1 << 24, 1 << 16, 1 << 8], np.uint32)).sum(-1).astype(np.uint32).reshape(-1)
 only = sys.argv[1:]   # e.g. "fuse=1,graph=0": run just that variant (for rocprofv3 --stats)
-variants = [dict(tfl_fuse=f, tfl_graph=g, tfl_streams=st, tfl_dot=dot, tfl_group=gr) for f, g, st, dot, gr in ((1, 0, 1, 2, 0), (1, 0, 1, 3, 0), (1, 0, 1, 3, 1), (0, 0, 1, 3, 1), (1, 1, 1, 3, 1), (1, 0, 4, 3, 0))]
+variants = [dict(tfl_fuse=f, tfl_graph=g, tfl_dot=dot, tfl_group=gr) for f, g, dot, gr in ((1, 0, 2, 0), (1, 0, 3, 0), (1, 0, 3, 1), (0, 0, 3, 1), (1, 1, 3, 1))]
 if only:
     kv = dict(p.split("=") for p in only[0].split(","))
-    variants = [dict(tfl_fuse=int(kv["fuse"]), tfl_graph=int(kv["graph"]), tfl_streams=int(kv.get("streams", 1)), tfl_dot=int(kv.get("dot", 3)), tfl_group=int(kv.get("group", 1)))]
+    variants = [dict(tfl_fuse=int(kv["fuse"]), tfl_graph=int(kv["graph"]), tfl_dot=int(kv.get("dot", 3)), tfl_group=int(kv.get("group", 1)))]
 engs = [(v, ya.TfliteEngine(buf, tune=v)) for v in variants]
 for v, e in engs:
     print(v, e.plan_summary(), flush=True)
@@ -35,4 +35,4 @@ for rnd in range(6):
             f = frame.copy(); t0 = time.perf_counter(); e.classify_frame(f, 640, 480, ya.COMPAT_SANE); t.append(time.perf_counter() - t0)
         res[i][1].append(np.median(t) * 1e3)
 for i, (v, e) in enumerate(engs):
-    print(f"tfl_fuse={v['tfl_fuse']} tfl_graph={v['tfl_graph']} tfl_streams={v['tfl_streams']} tfl_dot={v['tfl_dot']} tfl_group={v['tfl_group']}: invoke {np.median(res[i][0]):.3f} ms (min {min(res[i][0]):.3f}), classify 640x480 {np.median(res[i][1]):.3f} ms (min {min(res[i][1]):.3f})", flush=True)
+    print(f"tfl_fuse={v['tfl_fuse']} tfl_graph={v['tfl_graph']} tfl_dot={v['tfl_dot']} tfl_group={v['tfl_group']}: invoke {np.median(res[i][0]):.3f} ms (min {min(res[i][0]):.3f}), classify 640x480 {np.median(res[i][1]):.3f} ms (min {min(res[i][1]):.3f})", flush=True)
