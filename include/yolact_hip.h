@@ -451,6 +451,14 @@ int yh_debug_alloc_map(yh_engine* h, char* out, size_t cap);
  * jobs run by group worker threads, out[2] times one of the former overlapped one of the latter anywhere in the process (must stay 0),
  * out[3] sections / jobs in flight right now. */
 int yh_debug_setup_audit(int64_t out[4]);
+/* Test hook, process-wide: allow = 1 lets yh_group_broadcast_weights / yh_group_replicate_weights treat handles that share a device as
+ * separate RCCL ranks. Real RCCL refuses two ranks on one GPU, so this is only meaningful under the stand-in librccl of
+ * tests/rccl_standin/ (which is how a one-GPU box executes the n > 1 collective code). Returns the previous setting. */
+int yh_debug_rccl_shared_device(int32_t allow);
+/* Test hook, process-wide, before the first RCCL call of the process (YH_ESTATE afterwards): open THIS file instead of searching for
+ * librccl.so.1. A process that has torch loaded already holds torch's bundled librccl under that soname, so the loader's search path
+ * cannot reach the stand-in there (bench.py --rccl-library); processes without torch find it through LD_LIBRARY_PATH, hook unused. */
+int yh_debug_rccl_library(const char* path);
 int yh_debug_graph_nodes(yh_engine* h, int32_t with_tail, char* out, size_t cap);
 
 /* ---- single-op entry points (parity tests call kernels through the C ABI) ------------------- */

@@ -123,7 +123,11 @@ def test_roofline_groups_by_tile_family_and_records_say_how_weights_were_replica
     import bench
     assert bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>[+1x1]") == "conv_igemm_f16<256,256,2,4,0,2>"
     assert bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>[ml]") == bench.kernel_family("conv_igemm_f16<256,256,2,4,0,2,mfma16>")
-    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1>[3x3]") == "conv_igemm_f16<128,128,2,2,0,1>" != bench.kernel_family("conv_igemm_f16<128,128,2,2,0,2>")
+    # round 5: a single-stage streaming tile is two populations with two bounds - its 3x3 launches are a family of their own
+    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1>[3x3]") == "conv_igemm_f16<128,128,2,2,0,1>[3x3]" != bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1>")
+    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1,dual>") == bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1,resup>") == "conv_igemm_f16<128,128,2,2,0,1>"
+    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,1>[ml][3x3]") == "conv_igemm_f16<128,128,2,2,0,1>[3x3]"
+    assert bench.kernel_family("conv_igemm_f16<128,128,2,2,0,2>[3x3]") == "conv_igemm_f16<128,128,2,2,0,2>"   # (pipelined tiles: one bound)
     assert bench.kernel_family("bneck_chain_f16<64,256,next>") == "bneck_chain_f16<64,256,next>" and bench.kernel_family("det_masks") == "det_masks"
     prof = [dict(name="conv_igemm_f16<128,128,2,2,0,1>:a", ms=2.0, flops=1e12, bytes=6e9),
             dict(name="conv_igemm_f16<256,256,2,4,0,2,mfma16>:p", ms=1.5, flops=1.5e12, bytes=1e9),
@@ -132,6 +136,12 @@ def test_roofline_groups_by_tile_family_and_records_say_how_weights_were_replica
     r = bench.roofline_of(prof, 64)
     assert r["kernel"] == "conv_igemm_f16<256,256,2,4,0,2>" and r["launches"] == 3 and r["bound"] == "mfma" and len(r["symbols"]) == 3
     assert abs(r["share_of_step"] - 3.6 / 5.6) < 1e-3 and abs(r["achieved"] - 3.8e12 / 3.6e-3 / 1e12) < 0.5
+    # the two largest families, each with ONE bound: a tie that flips by box changes their order, not what is reported
+    prof2 = prof + [dict(name="conv_igemm_f16<128,128,2,2,0,1>[3x3]:b", ms=1.0, flops=0.9e12, bytes=0.3e9)]
+    r1, r2 = bench.roofline_of(prof2, 64), bench.roofline_of(prof2, 64, rank=1)
+    assert r1["kernel"] == "conv_igemm_f16<256,256,2,4,0,2>" and r2["kernel"] == "conv_igemm_f16<128,128,2,2,0,1>" and r2["bound"] == "hbm" and r2["launches"] == 1
+    r3 = bench.roofline_of(prof2, 64, rank=2)
+    assert r3["kernel"] == "conv_igemm_f16<128,128,2,2,0,1>[3x3]" and r3["bound"] == "mfma" and bench.roofline_of(prof2, 64, rank=9) is None
     fams = bench.family_rooflines(prof)
     assert [f["kernel"] for f in fams][0] == "conv_igemm_f16<128,128,2,2,0,1>" and all("family" in f for f in fams)
     src = open(os.path.join(ROOT, "bench.py")).read()

@@ -35,6 +35,8 @@ const RoctxApi& roctx_api() {   // resolved once per process (C++11 static initi
     return api;
 }
 SetupAudit& setup_audit() { static SetupAudit a; return a; }
+static std::atomic<int> g_rccl_shared_device{0};
+bool rccl_shared_device_allowed() { return g_rccl_shared_device.load() != 0; }
 }  // namespace yh
 
 namespace {
@@ -1904,15 +1906,19 @@ struct Rccl {
     std::string err;
 };
 void rccl_open(Rccl& r);
+std::atomic<int> g_rccl_opened{0};
+std::string& rccl_path_override() { static std::string s; return s; }   // yh_debug_rccl_library (tests: the stand-in of tests/rccl_standin/, by path)
 Rccl* rccl() {   // opened once per process (thread-safe: C++11 static initialisation); a failed open is remembered with its reason
-    static Rccl r = [] { Rccl x; rccl_open(x); return x; }();
+    static Rccl r = [] { Rccl x; g_rccl_opened.store(1); rccl_open(x); return x; }();
     return &r;
 }
 void rccl_open(Rccl& r) {
-    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
-    }
+    if (!rccl_path_override().empty()) r.lib = dlopen(rccl_path_override().c_str(), RTLD_NOW | RTLD_LOCAL);
+    else
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
     if (!r.lib) { const char* why = dlerror(); r.err = std::string("dlopen librccl.so: ") + (why ? why : "not found"); return; }
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl.so lacks ") + n; return p; };
     r.GetUniqueId = (int (*)(RcclId*))sym("ncclGetUniqueId");
@@ -1975,7 +1981,7 @@ int yh_group_broadcast_weights(yh_engine** hs, int32_t n, int32_t root) {
     if (!h0->weights_loaded) return h0->fail(YH_ESTATE, "the root handle must have its weights loaded before the broadcast");
     for (int i = 0; i < n; ++i) {
         if (hs[i]->blob_bytes != h0->blob_bytes) return h0->fail(YH_EINVAL, "handles of one group must share the architecture");
-        for (int j = 0; j < i; ++j) if (hs[j]->dev == hs[i]->dev) return h0->fail(YH_EINVAL, "one handle per device: RCCL refuses two ranks on one GPU");
+        for (int j = 0; j < i; ++j) if (hs[j]->dev == hs[i]->dev && !yh::rccl_shared_device_allowed()) return h0->fail(YH_EINVAL, "one handle per device: RCCL refuses two ranks on one GPU");
     }
     if (n == 1) return YH_OK;
     Rccl* r = rccl();
@@ -2080,6 +2086,15 @@ int yh_prepare(yh_engine* h, int32_t n_frames, int32_t with_tail) {
     h->in_cur = cur;
     return rc;
 }
+
+int yh_debug_rccl_library(const char* path) {
+    if (!path || !*path) return YH_EINVAL;
+    if (g_rccl_opened.load()) { g_create_error = "librccl has already been opened in this process"; return YH_ESTATE; }
+    rccl_path_override() = path;
+    return YH_OK;
+}
+
+int yh_debug_rccl_shared_device(int32_t allow) { return yh::g_rccl_shared_device.exchange(allow ? 1 : 0); }
 
 int yh_debug_setup_audit(int64_t out[4]) {
     if (!out) return YH_EINVAL;

@@ -160,7 +160,7 @@ int yh_group_replicate_weights(yh_group* g) {
     // one representative per distinct device, member 0 first
     std::vector<int> rep, rep_of(n, -1);
     for (int i = 0; i < n; ++i) {
-        for (int r : rep) if (g->dev[r] == g->dev[i]) rep_of[i] = r;
+        for (int r : rep) if (g->dev[r] == g->dev[i] && !yh::rccl_shared_device_allowed()) rep_of[i] = r;
         if (rep_of[i] < 0) { rep_of[i] = i; rep.push_back(i); }
     }
     std::string how;

@@ -10,8 +10,13 @@
 // centroids are exact integer means. Integer outputs and every float are bit-identical to the oracle: one IEEE
 // operation per operator (-ffp-contract=off; sqrtf and / are correctly rounded in HIP by default, unlike __fsqrt_rn,
 // which maps to the native approximate instruction).
-// HBM / atomic-bound byte work: one lane per pixel, 8x8 workgroups as the dispatch the reference uses; the height map
-// is built with atomicMax on 32-bit words as the shader's imageAtomicMax does.
+// Atomic-bound byte work. The height map is a max over ~150 M bump taps per 640 x 480 frame; the shader (and rounds 2-4 here)
+// gives every pixel a lane that walks its 400 / 1 600 taps through imageAtomicMax in global memory (2.0-2.3 ms per frame). Round 5
+// (scene_cloud_strips): the map is PRIVATISED in LDS - a workgroup owns a strip of 16 pixel columns x a band of 64 map rows, stamps
+// every tap that lands there with ds_max_u32 (a wave per pixel, a lane per tap: uniform tap counts, coalesced table reads,
+// consecutive lanes on consecutive LDS words) and merges its image into the global map with one atomicMax per touched cell. A max
+// is order-free, so the result is the shader's imageAtomicMax result bit for bit. The other stages keep one lane per pixel in
+// 8x8 workgroups, the dispatch the reference uses (scene.rs:245,:256).
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -43,8 +48,8 @@ struct SceneParams {
     float4* balls;                // [100]
     // the bump profiles, tabulated once per handle: a tap's height depends only on (val, dx, dy), and val is the pixel's
     // ROW for terrain (pt_cloud.comp:116) or the constant 100 for robots (:122)
-    const uint32_t* terrain_tab;  // [H][20][20]
-    const uint32_t* robot_tab;    // [40][40]
+    const uint32_t* terrain_tab;  // [H][ly 20][lx 20]
+    const uint32_t* robot_tab;    // [ly 40][lx 40]
 };
 
 // height of one bump tap (pt_cloud.comp:55-73): val / (1 + C_1^(C_2 prox - 1)), truncated; 0 where the shader's pow() is undefined
@@ -59,64 +64,111 @@ __device__ __forceinline__ uint32_t bump_tap(float val, int L, int lx, int ly) {
     return y_add >= 1.0f ? (uint32_t)y_add : 0u;
 }
 
-// one lane per table entry: terrain [H][2L][2L] with val = row, robot [2L][2L] with val = 100
+// one lane per table entry: terrain [H][ly][lx] with val = row, robot [ly][lx] with val = 100 (lx fastest: consecutive lanes of
+// scene_cloud_strips take consecutive lx = consecutive map columns)
 __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t* robot, int H) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int nt = H * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM, nr = 4 * SC_BOT_NORM * SC_BOT_NORM;
     if (t < nt) {
         const int y = t / (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM), r = t % (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM);
-        terrain[t] = bump_tap((float)y, SC_TERRAIN_NORM, r / (2 * SC_TERRAIN_NORM), r % (2 * SC_TERRAIN_NORM));
+        terrain[t] = bump_tap((float)y, SC_TERRAIN_NORM, r % (2 * SC_TERRAIN_NORM), r / (2 * SC_TERRAIN_NORM));
     } else if (t - nt < nr) {
         const int r = t - nt;
-        robot[r] = bump_tap(SC_BOT_AVOID, SC_BOT_NORM, r / (2 * SC_BOT_NORM), r % (2 * SC_BOT_NORM));
+        robot[r] = bump_tap(SC_BOT_AVOID, SC_BOT_NORM, r % (2 * SC_BOT_NORM), r / (2 * SC_BOT_NORM));
     }
 }
 
-// pt_cloud.comp:44-76 with the tap heights read from the table ([lx][ly]). imageAtomicMax is a max: a tap that does not
-// exceed what a read of the map already shows cannot change it (the map only grows within the launch, from the zeros the
-// memset left: whatever age the value read has, it is a lower bound of the cell), so only the other taps issue the atomic -
-// most taps of overlapping bumps lose, and the kernel stops being bound by 150 M atomics per frame.
-__device__ __forceinline__ void bump(const SceneParams& p, int px, int py, const uint32_t* tab, int L) {
-    for (int lx = 0; lx < 2 * L; ++lx)
-        for (int ly = 0; ly < 2 * L; ++ly) {
-            const int x = px - L + lx, y = py - L + ly;
-            if (x > 0 && y > 0 && x < p.W - 1 && y < p.H - 1) {
-                const uint32_t v = tab[lx * 2 * L + ly];
-                uint32_t* cell = p.map + (size_t)y * p.W + x;
-                if (v > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, v);
+// pt_cloud.comp main (:84-123) and its bump() (:44-76), privatised. Geometry of one workgroup (512 lanes, 8 waves):
+//   strip   pixel columns [c0, c0 + 16): a pixel (x, y) stamps around (nx, ny) = (x, H - dic(depth)), i.e. map columns
+//           x - L .. x + L - 1 with L <= 20: the strip's taps land in map columns [c0 - 20, c0 + 36) - the LDS image's 56 columns;
+//   band    map rows [r0, r0 + 64): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
+//           of each bump that fall into its own band; bands make the grid ~W/16 x H/64 = 320 workgroups at 640 x 480 and keep
+//           the image at 14 KB, several workgroups per CU.
+// Per batch of 64 pixels a lane computes one pixel's target and class (the shader's arithmetic, one IEEE operation per operator);
+// the wave then takes the batch's bump pixels one at a time (ballot + readlane: wave-uniform L, row range and table), lane t of
+// the wave owning tap t, t + 64, ...: the table read is coalesced, the LDS words of a tap row are consecutive (row pitch 57: odd,
+// the rows of one pixel start in different banks). A tap of height 0 changes nothing and is not issued. Ball pixels add their
+// position to 64-bit sums in LDS (band 0 only: once per pixel), flushed once per workgroup.
+#define SC_CW 16
+#define SC_BH 64
+#define SC_HALO 20
+#define SC_LDW (SC_CW + 2 * SC_HALO + 1)
+__global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
+    __shared__ uint32_t img[SC_BH * SC_LDW];
+    __shared__ unsigned long long ball[300];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * SC_CW, r0 = blockIdx.y * SC_BH;
+    const bool do_balls = blockIdx.y == 0;
+    for (int i = tid; i < SC_BH * SC_LDW; i += 512) img[i] = 0u;
+    if (do_balls) for (int i = tid; i < 300; i += 512) ball[i] = 0ull;
+    __syncthreads();
+    const int cw = min(SC_CW, p.W - c0), npix = cw * p.H;
+    const int band_lo = max(r0, 1), band_hi = min(r0 + SC_BH, p.H - 1);   // rows y with 0 < y < H - 1 inside the band
+    for (int b0 = wave * 64; b0 < npix; b0 += 8 * 64) {
+        const int k = b0 + lane;
+        int nx = 0, ny = 0, L = 0;
+        const uint32_t* tab = nullptr;
+        if (k < npix) {
+            const int y = k / cw, x = c0 + (k - y * cw);
+            const size_t i = (size_t)y * p.W + x;
+            const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
+            const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
+            const float cy = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(ty, ty))));
+            const float cx = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(tx, tx))));
+            const float d = __fmul_rn(__fmul_rn((float)p.depth[i], cy), cx);
+            const int dic = (int)__fdiv_rn(__fmul_rn((float)p.H, d), SC_MAX_DEPTH);
+            int cls, id;
+            if (p.cls_id) { cls = p.cls_id[2 * i]; id = p.cls_id[2 * i + 1]; }
+            else {
+                const uint32_t px = p.frame[i];
+                if (p.frame_mode == 0) { cls = (int)(px & 0xFFu); id = (int)((px >> 8) & 0xFFu); }   // `as u16` then R8G8 (scene.rs:93, :198)
+                else { cls = (int)(px >> 24); id = (int)((px >> 16) & 0xFFu); }
+            }
+            int action = cls;
+            if (action > 1) action = action - 1;
+            nx = x; ny = p.H - dic;
+            if (action == 0) { L = SC_TERRAIN_NORM; tab = p.terrain_tab + (size_t)y * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM; }
+            else if (action == 2) {
+                if (do_balls && id < 100) {
+                    __hip_atomic_fetch_add(&ball[id], (unsigned long long)(long long)nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&ball[100 + id], (unsigned long long)(long long)ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&ball[200 + id], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else { L = SC_BOT_NORM; tab = p.robot_tab; }
+        }
+        // this lane's bump meets the band?
+        const bool hit = L > 0 && max(ny - L, band_lo) < min(ny + L, band_hi);
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int jx = __builtin_amdgcn_readlane(nx, j), jy = __builtin_amdgcn_readlane(ny, j), jL = __builtin_amdgcn_readlane(L, j);
+            const unsigned long long tp = (unsigned long long)tab;
+            const uint32_t* jtab = (const uint32_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tp >> 32), j) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readlane((int)tp, j));
+            const int ya = max(jy - jL, band_lo), yb = min(jy + jL, band_hi), w2 = 2 * jL, total = (yb - ya) * w2;
+            const int xl = jx - jL;   // map column of lx = 0
+            for (int t = lane; t < total; t += 64) {
+                const int row = jL == SC_TERRAIN_NORM ? t / (2 * SC_TERRAIN_NORM) : t / (2 * SC_BOT_NORM);
+                const int lx = t - row * w2, y = ya + row, x = xl + lx;
+                if (x > 0 && x < p.W - 1) {
+                    const uint32_t v = jtab[(y - (jy - jL)) * w2 + lx];
+                    if (v) __hip_atomic_fetch_max(&img[(y - r0) * SC_LDW + (x - c0 + SC_HALO)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
-}
-
-// pt_cloud.comp main (:84-123)
-__global__ __launch_bounds__(64) void scene_cloud(const SceneParams p) {
-    const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
-    if (x >= p.W || y >= p.H) return;
-    const size_t i = (size_t)y * p.W + x;
-    const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
-    const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
-    const float cy = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(ty, ty))));
-    const float cx = __fdiv_rn(1.0f, __builtin_sqrtf(__fadd_rn(1.0f, __fmul_rn(tx, tx))));
-    const float d = __fmul_rn(__fmul_rn((float)p.depth[i], cy), cx);
-    const int dic = (int)__fdiv_rn(__fmul_rn((float)p.H, d), SC_MAX_DEPTH);
-    int cls, id;
-    if (p.cls_id) { cls = p.cls_id[2 * i]; id = p.cls_id[2 * i + 1]; }
-    else {
-        const uint32_t px = p.frame[i];
-        if (p.frame_mode == 0) { cls = (int)(px & 0xFFu); id = (int)((px >> 8) & 0xFFu); }   // `as u16` then R8G8 (scene.rs:93, :198)
-        else { cls = (int)(px >> 24); id = (int)((px >> 16) & 0xFFu); }
     }
-    int action = cls;
-    if (action > 1) action = action - 1;
-    const int nx = x, ny = p.H - dic;
-    if (action == 0) bump(p, nx, ny, p.terrain_tab + (size_t)y * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM, SC_TERRAIN_NORM);
-    else if (action == 2) {
-        if (id < 100) {
-            atomicAdd((unsigned long long*)p.ball_acc + id, (unsigned long long)(long long)nx);
-            atomicAdd((unsigned long long*)p.ball_acc + 100 + id, (unsigned long long)(long long)ny);
-            atomicAdd((unsigned long long*)p.ball_acc + 200 + id, 1ull);
+    __syncthreads();
+    for (int i = tid; i < SC_BH * SC_LDW; i += 512) {
+        const uint32_t v = img[i];
+        if (v) {
+            const int row = i / SC_LDW, col = i - row * SC_LDW;
+            atomicMax(p.map + (size_t)(r0 + row) * p.W + (c0 - SC_HALO + col), v);
         }
-    } else bump(p, nx, ny, p.robot_tab, SC_BOT_NORM);
+    }
+    if (do_balls)
+        for (int i = tid; i < 300; i += 512)
+            if (ball[i]) atomicAdd((unsigned long long*)p.ball_acc + i, ball[i]);
 }
 
 __global__ void scene_balls(const SceneParams p) {
@@ -213,7 +265,7 @@ int run_scene(yh_scene* h, const uint16_t* depth_dev, const uint8_t* cls_dev, co
     SCHK(h, hipMemsetAsync(h->map, 0, npx * 4, h->stream));
     SCHK(h, hipMemsetAsync(h->ball_acc, 0, 300 * sizeof(long long), h->stream));
     const dim3 grid((unsigned)((h->W + 7) / 8), (unsigned)((h->H + 7) / 8)), block(8, 8);   // [80,60,1] x 8x8 at 640x480 (scene.rs:245,:256)
-    hipLaunchKernelGGL(scene_cloud, grid, block, 0, h->stream, p);
+    hipLaunchKernelGGL(scene_cloud_strips, dim3((unsigned)((h->W + SC_CW - 1) / SC_CW), (unsigned)((h->H + SC_BH - 1) / SC_BH)), dim3(512), 0, h->stream, p);
     hipLaunchKernelGGL(scene_balls, dim3(1), dim3(128), 0, h->stream, p);
     hipLaunchKernelGGL(scene_world, grid, block, 0, h->stream, p);
     hipLaunchKernelGGL(scene_conn1, grid, block, 0, h->stream, p);

@@ -52,6 +52,7 @@ struct WorkerScope {
 void engine_set_worker_mode(yh_engine* h, bool on);
 bool engine_step_prepared(const yh_engine* h, int n_frames, int with_tail);   // eager handles: always true
 bool engine_uses_graph(const yh_engine* h);
+bool rccl_shared_device_allowed();   // yh_debug_rccl_shared_device (tests with a stand-in librccl: several ranks on one device)
 
 // ---------------------------------------------------------------------------------------------
 // Convolution as implicit GEMM (conv_igemm.hip).

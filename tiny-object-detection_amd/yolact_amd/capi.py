@@ -153,6 +153,8 @@ SYMBOLS = [
     ("yh_debug_last_conv_launches", _i, [_vp]),
     ("yh_debug_alloc_map", _i, [_vp, C.c_char_p, _sz]),
     ("yh_debug_setup_audit", _i, [C.POINTER(C.c_int64 * 4)]),
+    ("yh_debug_rccl_shared_device", _i, [_i]),
+    ("yh_debug_rccl_library", _i, [C.c_char_p]),
     ("yh_debug_graph_nodes", _i, [_vp, _i, C.c_char_p, _sz]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
