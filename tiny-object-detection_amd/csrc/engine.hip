@@ -1853,13 +1853,18 @@ int yh_weights_generate(const yh_engine* hc, uint64_t seed, void* blob_host, siz
     return YH_OK;
 }
 
+// The handle's copy of the canonical blob in device memory (the send / receive buffer of the weight broadcast): allocated on first use.
+static int ensure_blob(yh_engine* h) {
+    if (h->blob_dev) return YH_OK;
+    void* q = nullptr;
+    const int rc = dev_alloc(h, &q, h->blob_bytes);
+    if (rc) return rc;
+    h->blob_dev = (uint8_t*)q;
+    return YH_OK;
+}
 static int keep_blob(yh_engine* h, const void* src, hipMemcpyKind kind) {
-    if (!h->blob_dev) {
-        void* q = nullptr;
-        const int rc = dev_alloc(h, &q, h->blob_bytes);
-        if (rc) return rc;
-        h->blob_dev = (uint8_t*)q;
-    }
+    const int rc = ensure_blob(h);
+    if (rc) return rc;
     if (src != h->blob_dev) HIPCHK(h, hipMemcpy(h->blob_dev, src, h->blob_bytes, kind));
     return YH_OK;
 }
@@ -1959,7 +1964,10 @@ int yh_rank_broadcast_weights(yh_engine* h, const void* id_bytes, int32_t rank, 
     Rccl* r = rccl();
     if (!r->err.empty()) return h->fail(YH_EHIP, r->err);
     HIPCHK(h, hipSetDevice(h->dev));
-    int rc = rank == root ? YH_OK : keep_blob(h, h->blob_dev, hipMemcpyDeviceToDevice);   // non-root: allocate the receive buffer
+    // non-root: the receive buffer. (Round 5, the first execution with two ranks - behind the stand-in librccl of tests/rccl_standin/ -
+    // found this line as keep_blob(h, h->blob_dev, ...): the argument was read, still null, before the allocation inside, and every
+    // rank that had never held weights failed with "hipMemcpy: invalid argument" - the path could not have worked on an 8-GPU node.)
+    int rc = rank == root ? YH_OK : ensure_blob(h);
     if (rc) return rc;
     RcclId id;
     memcpy(&id, id_bytes, sizeof id);
@@ -1989,7 +1997,11 @@ int yh_group_broadcast_weights(yh_engine** hs, int32_t n, int32_t root) {
     std::vector<int> devs(n);
     for (int i = 0; i < n; ++i) {
         devs[i] = hs[i]->dev;
-        if (i != root) { HIPCHK(hs[i], hipSetDevice(hs[i]->dev)); const int rc = keep_blob(hs[i], hs[i]->blob_dev, hipMemcpyDeviceToDevice); if (rc) return rc; }
+        if (i != root) {
+            if (hipSetDevice(hs[i]->dev) != hipSuccess) return h0->fail(YH_EHIP, "hipSetDevice failed for handle " + std::to_string(i));
+            const int rc = ensure_blob(hs[i]);
+            if (rc) return h0->fail(rc, "handle " + std::to_string(i) + ": " + hs[i]->err);   // (the caller reads the ROOT handle's error)
+        }
     }
     std::vector<rccl_comm> comms(n, nullptr);
     int e = r->CommInitAll(comms.data(), n, devs.data());
@@ -2004,7 +2016,11 @@ int yh_group_broadcast_weights(yh_engine** hs, int32_t n, int32_t root) {
     if (e) return h0->fail(YH_EHIP, rccl_msg(r, "ncclBroadcast (group)", e));
     if (se != hipSuccess) return h0->fail(YH_EHIP, std::string("weight broadcast: ") + hipGetErrorString(se));
     for (int i = 0; i < n; ++i)
-        if (i != root) { HIPCHK(hs[i], hipSetDevice(hs[i]->dev)); const int rc = adopt_received_blob(hs[i]); if (rc) return rc; }
+        if (i != root) {
+            if (hipSetDevice(hs[i]->dev) != hipSuccess) return h0->fail(YH_EHIP, "hipSetDevice failed for handle " + std::to_string(i));
+            const int rc = adopt_received_blob(hs[i]);
+            if (rc) return h0->fail(rc, "handle " + std::to_string(i) + ": " + hs[i]->err);
+        }
     return YH_OK;
 }
 
