@@ -84,15 +84,23 @@ __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t*
 //   band    map rows [r0, r0 + 64): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
 //           of each bump that fall into its own band; bands make the grid ~W/16 x H/64 = 320 workgroups at 640 x 480 and keep
 //           the image at 14 KB, several workgroups per CU.
-// Per batch of 64 pixels a lane computes one pixel's target and class (the shader's arithmetic, one IEEE operation per operator);
-// the wave then takes the batch's bump pixels one at a time (ballot + readlane: wave-uniform L, row range and table), lane t of
-// the wave owning tap t, t + 64, ...: the table read is coalesced, the LDS words of a tap row are consecutive (row pitch 57: odd,
-// the rows of one pixel start in different banks). A tap of height 0 changes nothing and is not issued. Ball pixels add their
-// position to 64-bit sums in LDS (band 0 only: once per pixel), flushed once per workgroup.
+// A wave takes pixel rows y = wave, wave + 8, ...: lanes 0-15 compute the row's 16 pixels (the shader's arithmetic, one IEEE
+// operation per operator), then the wave stamps the row's bump pixels one at a time (ballot + readlane: wave-uniform target),
+// lane t owning taps t, t + 64, ... of the bump. The tap HEIGHTS sit in registers: a terrain tap depends on the pixel's row only
+// (pt_cloud.comp:116), so the row's 400-entry table is loaded once per row (7 coalesced loads, only if some pixel of the row hits
+// the band) and serves its 16 pixels; the robot table (1 600 entries, a constant) is loaded once per workgroup (25 registers). The
+// stamping loop therefore has no memory read: per tap a range test and one ds_max_u32 (row pitch 57: odd). A tap of height 0
+// changes nothing and is not issued. (First version of this kernel, a wave per pixel with the table read from global memory inside
+// the tap loop: 0.56-0.65 ms per frame against 2.0-2.3 for the global-atomic form; it waited for one L2 round trip per 64 taps.)
+// Ball pixels add their position to 64-bit sums in LDS (band 0 only: once per pixel), flushed once per workgroup.
 #define SC_CW 16
 #define SC_BH 64
 #define SC_HALO 20
 #define SC_LDW (SC_CW + 2 * SC_HALO + 1)
+#define SC_TT (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM)   // 400 taps
+#define SC_RT (4 * SC_BOT_NORM * SC_BOT_NORM)           // 1600 taps
+#define SC_TK ((SC_TT + 63) / 64)                       // 7 taps per lane
+#define SC_RK (SC_RT / 64)                              // 25 taps per lane
 __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
     __shared__ uint32_t img[SC_BH * SC_LDW];
     __shared__ unsigned long long ball[300];
@@ -101,15 +109,17 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
     const bool do_balls = blockIdx.y == 0;
     for (int i = tid; i < SC_BH * SC_LDW; i += 512) img[i] = 0u;
     if (do_balls) for (int i = tid; i < 300; i += 512) ball[i] = 0ull;
+    uint32_t rt[SC_RK];   // the robot bump, this lane's taps
+#pragma unroll
+    for (int k = 0; k < SC_RK; ++k) rt[k] = p.robot_tab[lane + 64 * k];
     __syncthreads();
-    const int cw = min(SC_CW, p.W - c0), npix = cw * p.H;
+    const int cw = min(SC_CW, p.W - c0);
     const int band_lo = max(r0, 1), band_hi = min(r0 + SC_BH, p.H - 1);   // rows y with 0 < y < H - 1 inside the band
-    for (int b0 = wave * 64; b0 < npix; b0 += 8 * 64) {
-        const int k = b0 + lane;
+    const int ibase = -r0 * SC_LDW - (c0 - SC_HALO);                       // img[ibase + y * SC_LDW + x] = the cell of map (x, y)
+    for (int y = wave; y < p.H; y += 8) {
         int nx = 0, ny = 0, L = 0;
-        const uint32_t* tab = nullptr;
-        if (k < npix) {
-            const int y = k / cw, x = c0 + (k - y * cw);
+        if (lane < cw) {
+            const int x = c0 + lane;
             const size_t i = (size_t)y * p.W + x;
             const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
             const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
@@ -127,34 +137,45 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
             int action = cls;
             if (action > 1) action = action - 1;
             nx = x; ny = p.H - dic;
-            if (action == 0) { L = SC_TERRAIN_NORM; tab = p.terrain_tab + (size_t)y * 4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM; }
+            if (action == 0) L = SC_TERRAIN_NORM;
             else if (action == 2) {
                 if (do_balls && id < 100) {
                     __hip_atomic_fetch_add(&ball[id], (unsigned long long)(long long)nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&ball[100 + id], (unsigned long long)(long long)ny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&ball[200 + id], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            } else { L = SC_BOT_NORM; tab = p.robot_tab; }
+            } else L = SC_BOT_NORM;
         }
-        // this lane's bump meets the band?
-        const bool hit = L > 0 && max(ny - L, band_lo) < min(ny + L, band_hi);
-        unsigned long long todo = __ballot(hit);
-        while (todo) {
-            const int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int jx = __builtin_amdgcn_readlane(nx, j), jy = __builtin_amdgcn_readlane(ny, j), jL = __builtin_amdgcn_readlane(L, j);
-            const unsigned long long tp = (unsigned long long)tab;
-            const uint32_t* jtab = (const uint32_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tp >> 32), j) << 32) |
-                                                     (unsigned)__builtin_amdgcn_readlane((int)tp, j));
-            const int ya = max(jy - jL, band_lo), yb = min(jy + jL, band_hi), w2 = 2 * jL, total = (yb - ya) * w2;
-            const int xl = jx - jL;   // map column of lx = 0
-            for (int t = lane; t < total; t += 64) {
-                const int row = jL == SC_TERRAIN_NORM ? t / (2 * SC_TERRAIN_NORM) : t / (2 * SC_BOT_NORM);
-                const int lx = t - row * w2, y = ya + row, x = xl + lx;
-                if (x > 0 && x < p.W - 1) {
-                    const uint32_t v = jtab[(y - (jy - jL)) * w2 + lx];
-                    if (v) __hip_atomic_fetch_max(&img[(y - r0) * SC_LDW + (x - c0 + SC_HALO)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool hit = L > 0 && max(ny - L, band_lo) < min(ny + L, band_hi);   // this lane's bump meets the band
+        unsigned long long todo_t = __ballot(hit && L == SC_TERRAIN_NORM), todo_r = __ballot(hit && L == SC_BOT_NORM);
+        if (todo_t) {
+            uint32_t tt[SC_TK];   // the terrain bump of THIS row, this lane's taps
+            const uint32_t* trow = p.terrain_tab + (size_t)y * SC_TT;
+#pragma unroll
+            for (int k = 0; k < SC_TK; ++k) tt[k] = lane + 64 * k < SC_TT ? trow[lane + 64 * k] : 0u;
+            while (todo_t) {
+                const int j = __ffsll((long long)todo_t) - 1;
+                todo_t &= todo_t - 1;
+                const int x0 = __builtin_amdgcn_readlane(nx, j) - SC_TERRAIN_NORM, y0 = __builtin_amdgcn_readlane(ny, j) - SC_TERRAIN_NORM;
+#pragma unroll
+                for (int k = 0; k < SC_TK; ++k) {
+                    const int t = lane + 64 * k, ly = t / (2 * SC_TERRAIN_NORM), lx = t - ly * (2 * SC_TERRAIN_NORM);
+                    const int yy = y0 + ly, xx = x0 + lx;
+                    if (tt[k] && yy >= band_lo && yy < band_hi && xx > 0 && xx < p.W - 1)
+                        __hip_atomic_fetch_max(&img[ibase + yy * SC_LDW + xx], tt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+            }
+        }
+        while (todo_r) {
+            const int j = __ffsll((long long)todo_r) - 1;
+            todo_r &= todo_r - 1;
+            const int x0 = __builtin_amdgcn_readlane(nx, j) - SC_BOT_NORM, y0 = __builtin_amdgcn_readlane(ny, j) - SC_BOT_NORM;
+#pragma unroll
+            for (int k = 0; k < SC_RK; ++k) {
+                const int t = lane + 64 * k, ly = t / (2 * SC_BOT_NORM), lx = t - ly * (2 * SC_BOT_NORM);
+                const int yy = y0 + ly, xx = x0 + lx;
+                if (rt[k] && yy >= band_lo && yy < band_hi && xx > 0 && xx < p.W - 1)
+                    __hip_atomic_fetch_max(&img[ibase + yy * SC_LDW + xx], rt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
