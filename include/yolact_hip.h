@@ -451,6 +451,15 @@ int yh_debug_alloc_map(yh_engine* h, char* out, size_t cap);
  * jobs run by group worker threads, out[2] times one of the former overlapped one of the latter anywhere in the process (must stay 0),
  * out[3] sections / jobs in flight right now. */
 int yh_debug_setup_audit(int64_t out[4]);
+/* Study hook (tools/study/cu_mask_scaling.py, profiles/r05_overlap.txt): re-creates the handle's two compute streams with
+ * hipExtStreamCreateWithCUMask - bit i of mask[] enables CU i (the driver deals the bits over the XCDs round-robin) - and drops the
+ * captured steps. How every kernel of a step scales with the CUs it is given is what decides whether two engines on disjoint CU
+ * sets can overlap the step's memory-bound and matrix-bound phases. */
+int yh_debug_set_cu_mask(yh_engine* h, const uint32_t* mask, int32_t n_words);
+/* ... and one PHASE of the forward for the frames last set, `reps` times back to back, eagerly on the handle's stream (timing only: the
+ * second phase reads whatever the first last left): phase 0 = backbone + FPN laterals (the memory-bound half of a batch-64 step),
+ * phase 1 = the FPN's 3x3 convolutions, the protonet and the prediction head (the matrix-bound half). *ms_total: device time. */
+int yh_debug_run_phase(yh_engine* h, int32_t phase, int32_t reps, float* ms_total);
 /* Test hook, process-wide: allow = 1 lets yh_group_broadcast_weights / yh_group_replicate_weights treat handles that share a device as
  * separate RCCL ranks. Real RCCL refuses two ranks on one GPU, so this is only meaningful under the stand-in librccl of
  * tests/rccl_standin/ (which is how a one-GPU box executes the n > 1 collective code). Returns the previous setting. */

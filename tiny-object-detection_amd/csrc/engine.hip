@@ -2103,6 +2103,44 @@ int yh_prepare(yh_engine* h, int32_t n_frames, int32_t with_tail) {
     return rc;
 }
 
+int yh_debug_set_cu_mask(yh_engine* h, const uint32_t* mask, int32_t n_words) {
+    if (!h || !mask || n_words < 1 || n_words > 16) return YH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->side));
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // captured for the old streams
+    h->graphs.clear();
+    hipStream_t ns = nullptr, nd = nullptr;
+    HIPCHK(h, hipExtStreamCreateWithCUMask(&ns, (uint32_t)n_words, mask));
+    HIPCHK(h, hipExtStreamCreateWithCUMask(&nd, (uint32_t)n_words, mask));
+    hipStreamDestroy(h->stream); hipStreamDestroy(h->side);
+    h->stream = ns; h->side = nd;
+    return YH_OK;
+}
+
+int yh_debug_run_phase(yh_engine* h, int32_t phase, int32_t reps, float* ms_total) {
+    if (!h || reps < 1 || (phase != 0 && phase != 1)) return YH_EINVAL;
+    if (!h->weights_loaded || h->cur_n < 1) return h->fail(YH_ESTATE, "weights and an input first");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = wait_input(h);
+    if (rc) return rc;
+    size_t p3 = h->ops.size();
+    for (size_t i = 0; i < h->ops.size(); ++i) if (h->ops[i].name == "p3") { p3 = i; break; }
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r)
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const bool second = i >= p3 || h->ops[i].side;   // p3, the FPN's P4..P7 convolutions, the head, the protonet
+            if (second != (phase == 1)) continue;
+            if ((rc = launch_op(h, h->ops[i], h->cur_n, false))) return rc;
+        }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.0f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (ms_total) *ms_total = ms;
+    return YH_OK;
+}
+
 int yh_debug_rccl_library(const char* path) {
     if (!path || !*path) return YH_EINVAL;
     if (g_rccl_opened.load()) { g_create_error = "librccl has already been opened in this process"; return YH_ESTATE; }

@@ -155,6 +155,8 @@ SYMBOLS = [
     ("yh_debug_setup_audit", _i, [C.POINTER(C.c_int64 * 4)]),
     ("yh_debug_rccl_shared_device", _i, [_i]),
     ("yh_debug_rccl_library", _i, [C.c_char_p]),
+    ("yh_debug_set_cu_mask", _i, [_vp, _vp, _i]),
+    ("yh_debug_run_phase", _i, [_vp, _i, _i, C.POINTER(_f)]),
     ("yh_debug_graph_nodes", _i, [_vp, _i, C.c_char_p, _sz]),
     ("yh_op_stem_pool_f16", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("yh_op_stem_pool_rgb8", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -375,6 +377,20 @@ class Engine:
 
     def evaluate(self):
         self._chk(self.L.yh_evaluate(self.h))
+
+    def set_cu_mask(self, n_cus, total=256, offset=0):
+        """Study hook: the handle's compute streams on CUs offset .. offset + n_cus - 1 of `total` (yh_debug_set_cu_mask)."""
+        words = (total + 31) // 32
+        m = (C.c_uint32 * words)()
+        for i in range(offset, offset + n_cus):
+            m[i // 32] |= 1 << (i % 32)
+        self._chk(self.L.yh_debug_set_cu_mask(self.h, C.cast(m, C.c_void_p), words))
+
+    def run_phase(self, phase, reps=1):
+        """Study hook: device ms of `reps` runs of one phase of the forward (yh_debug_run_phase)."""
+        ms = C.c_float()
+        self._chk(self.L.yh_debug_run_phase(self.h, phase, reps, C.byref(ms)))
+        return ms.value
 
     def prepare(self, n, with_tail=True):
         """yh_prepare: capture the step for n frames now, on this thread (allocate_tensors() at its proper time)."""
