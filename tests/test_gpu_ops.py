@@ -114,6 +114,36 @@ def test_conv_split_launch_plans_exact_on_integers(eng, oracle, cin, cout, k, n,
     assert np.array_equal(split, yo) and np.array_equal(single, yo)
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_head_remainder_on_96_channel_tiles_exact_on_integers(eng, oracle, k):
+    """Round 5: the shared head's 351 channels run as a 256-wide launch plus a launch for channels 256 .. 350 - 95 of them - which in its
+    multi-level streaming form takes 96-channel tiles (conv_igemm_f16<96,128,...,mfma16>, a channel base that is no multiple of
+    the tile) instead of 128-channel ones. Reached with small tensors by planning for a 4-CU chip; every level equal to the
+    oracle's convolution of that level alone, bit for bit (channel 351 of the padded row must stay untouched: the op's rows are
+    352 wide and are compared whole), and equal to the 128-channel form (tune.chsplit = 2)."""
+    rng = np.random.default_rng(96 + k)
+    sizes, n, cin, cout = [13, 9, 5, 3], 6, 64 if k == 3 else 512, 351       # 284 cells x 6 = 1704 rows: 7 row tiles of 256
+    cells = sum(s * s for s in sizes)
+    x = rng.integers(-3, 4, (n, cells, cin)).astype(np.float32)
+    wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    outs = {}
+    for chsplit in (1, 2):
+        eng.set_tuning(plan_cus=4, chsplit=chsplit)
+        try:
+            outs[chsplit] = eng.op_conv2d_levels(x, sizes, wt, b, act=1)
+            assert eng.last_conv_launches() == 2
+        finally:
+            eng.reset_tuning("plan_cus", "chsplit")
+    off = 0
+    for s_ in sizes:
+        xl = x[:, off:off + s_ * s_].reshape(n, s_, s_, cin)
+        yo = oracle.conv2d(f16(xl), f16(wt), b, 1, k // 2, None, 1, f16=True).reshape(n, s_ * s_, cout)
+        assert np.array_equal(outs[1][:, off:off + s_ * s_], yo), s_
+        off += s_ * s_
+    assert np.array_equal(outs[1], outs[2])
+
+
 def test_conv_two_phase_plan_is_bitwise_identical_on_random_data(eng):
     """Random (non-exact) data: the tail phase's 128x128 16x16x32 tiles must accumulate each output
     element in the same order as the 256x256 tile, so the plan cannot change a single bit."""

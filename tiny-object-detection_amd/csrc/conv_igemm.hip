@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     int wk_shift = 0;   // DUAL: K index at which the current source's channels start in the weight panel
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
-    const unsigned wbase = (unsigned)(((ch_tile * TCH + rb) * p.ldw + lc * 8) * 2);
+    const unsigned wbase = (unsigned)(((p.ch_base + ch_tile * TCH + rb) * p.ldw + lc * 8) * 2);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char* const lds3 = (lds_char*)lds;
@@ -285,10 +285,12 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
     // ---- epilogue geometry is known up front; for single-round epilogues the residual rows are
     // requested NOW, so their HBM latency hides under the whole main loop (the residual 1x1 convs
     // have 1-4 k-steps: requested after the loop, that latency was fully exposed).
-    constexpr int TPR = TCH / 8, RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
+    // (lanes per output row: TCH / 8, rounded up to a power of two - the 96-channel tile keeps 12 of 16 busy)
+    constexpr int TPR = TCH / 8 <= 4 ? 4 : (TCH / 8 <= 8 ? 8 : (TCH / 8 <= 16 ? 16 : 32)), RPP = NT / TPR, EROWS = TM / EPI, NPASS = EROWS / RPP, WMG = WM / EPI;
+    static_assert(TCH / 8 <= 32 && NT % TPR == 0 && EROWS % RPP == 0, "epilogue geometry");
     const int ch_l = (tid % TPR) * 8, rr = tid / TPR;
-    const int ch = ch_tile * TCH + ch_l;
-    const bool ch_ok = ch < p.cout8;
+    const int ch = p.ch_base + ch_tile * TCH + ch_l;
+    const bool ch_ok = ch < p.cout8 && ch_l < TCH;
     auto offsets = [&](int m, long long& yo, long long& ro) {
         if (p.y_dense) {
             yo = (long long)m * p.ldy + ch;
@@ -889,11 +891,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
 
 int conv_tile_ch(ConvTile t) {
     switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_128x256: case TILE_128x256_M16: return 128; case TILE_64x256: case TILE_64x256_SMALLC: case TILE_64x256_K1: case TILE_64x64_S3: case TILE_64x64_FP8: return 64;
-                 case TILE_32x256: return 32; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
+                 case TILE_32x256: return 32; case TILE_96x128_K1: return 96; case TILE_256x256: case TILE_256x256_M16: case TILE_256x256_FP8: return 256; }
     return 0;
 }
 int conv_tile_m(ConvTile t) {
-    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: return 128; case TILE_64x64_S3: case TILE_64x64_FP8: return 64; default: return 256; }
+    switch (t) { case TILE_128x128: case TILE_128x128_S3: case TILE_128x128_M16: case TILE_128x128_S3_M16: case TILE_128x128_K1: case TILE_128x128_FP8: case TILE_96x128_K1: return 128; case TILE_64x64_S3: case TILE_64x64_FP8: return 64; default: return 256; }
 }
 const char* conv_tile_symbol(ConvTile t) {
     switch (t) {
@@ -910,6 +912,7 @@ const char* conv_tile_symbol(ConvTile t) {
         case TILE_128x256_M16: return "conv_igemm_f16<128,256,2,4,0,2,mfma16>";
         case TILE_64x64_S3: return "conv_igemm_f16<64,64,2,2,0,3>";
         case TILE_128x128_K1: return "conv_igemm_f16<128,128,2,2,0,1>";
+        case TILE_96x128_K1: return "conv_igemm_f16<96,128,2,2,0,1,mfma16>";
         case TILE_64x256_K1: return "conv_igemm_f16<64,256,1,4,0,1>";
         case TILE_256x256_FP8: return "conv_igemm_fp8<256,256,2,4>";
         case TILE_128x128_FP8: return "conv_igemm_fp8<128,128,2,2>";
@@ -953,6 +956,7 @@ hipError_t launch_conv(const ConvParams& p, ConvTile tile, hipStream_t stream) {
             case TILE_128x256: hipLaunchKernelGGL((conv_igemm_f16<128, 256, 2, 4, false, 3, 1, false, 32, true>), grid, dim3(512), 0, stream, p); break;
             case TILE_128x128: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_K1: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 1, 2, false, 32, true>), grid, dim3(256), 0, stream, p); break;
+            case TILE_96x128_K1: hipLaunchKernelGGL((conv_igemm_f16<96, 128, 2, 2, false, 1, 2, false, 16, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 32, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 2, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;
             case TILE_128x128_S3_M16: hipLaunchKernelGGL((conv_igemm_f16<128, 128, 2, 2, false, 3, 1, false, 16, true>), grid, dim3(256), 0, stream, p); break;

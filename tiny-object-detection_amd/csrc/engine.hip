@@ -885,7 +885,7 @@ int tail_split_tiles(const Tune& tu, int coutPad, const ConvParams& p, ConvTile 
 // algorithmic work a launch does (profile attribution), `what` a label suffix.
 struct KLaunch { bool reduce; ConvParams p; ConvTile tile; double frac; const char* what; };
 
-int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[2]) {
+int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, KLaunch out[3]) {
     if (p.k_slices > 1) {   // split-K: main kernel + slab reduction
         out[0] = KLaunch{ false, p, tile, 1.0, "/splitk" };
         out[1] = KLaunch{ true, p, tile, 0.0, "" };
@@ -901,11 +901,23 @@ int plan_conv(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, K
         ConvParams a = p, b = p;
         a.n_ch_tiles = 1;
         b.n_ch_tiles = 1; b.ch_tile0 = 2;
-        out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
         // the 128-channel remainder on the 4-wave 128 x 128 tile (two workgroups per CU: 0.34 -> 0.30 ms at batch 64), in its
         // streaming form where the launch is large (four per CU: 0.31 -> 0.26 ms)
-        out[1] = KLaunch{ false, b, tu.k1tile >= 6 && (long long)((p.M + 127) / 128) >= (long long)tu.k1_min3 * tu.plan_cus / 4 ? TILE_128x128_K1 : TILE_128x128, 128.0 / 384.0, "/ch256-383" };
-        return 2;
+        const bool streaming = tu.k1tile >= 6 && (long long)((p.M + 127) / 128) >= (long long)tu.k1_min3 * tu.plan_cus / 4;
+        // (round 5, measured and not kept: splitting the 256-wide launch's own last round off - head_out at batch 64 is 1 604 tiles =
+        // 6.27 rounds - onto the bit-compatible 128 x 128 tiles: 0.4415 + 0.0480 ms against 0.4912 for the single launch; and a last
+        // round up to three quarters full split off for p3 / proto0-2 (4.65 rounds): 0.276 + 0.075 against 0.341 ms, step 9.72 vs 9.67)
+        const int na = 1;
+        out[0] = KLaunch{ false, a, TILE_256x256_M16, 256.0 / 384.0, "/ch0-255" };
+        // (round 5: the remainder holds 351 - 256 = 95 channels: in the multi-level form its streaming launch runs on 96-channel tiles -
+        // a quarter fewer MFMAs than the 128-channel tile's; tune.chsplit = 2 keeps the 128-channel tile for the A/B)
+        if (streaming && p.nlev > 0 && chsplit == 1 && p.cout8 <= 352) {
+            b.ch_tile0 = 0; b.ch_base = 256;
+            out[na] = KLaunch{ false, b, TILE_96x128_K1, 128.0 / 384.0, "/ch256-351" };
+            return na + 1;
+        }
+        out[na] = KLaunch{ false, b, streaming ? TILE_128x128_K1 : TILE_128x128, 128.0 / 384.0, "/ch256-383" };
+        return na + 1;
     }
     const int mt1 = tail_split_tiles(tu, coutPad, p, tile);
     if (mt1 == 0) { out[0] = KLaunch{ false, p, tile, 1.0, "" }; return 1; }
@@ -927,7 +939,7 @@ hipError_t launch_k(const KLaunch& k, hipStream_t stream) {
 }
 
 hipError_t launch_conv_planned(const Tune& tu, const ConvParams& p, ConvTile tile, int coutPad, hipStream_t stream, int* n_launches = nullptr) {
-    KLaunch k[2];
+    KLaunch k[3];
     const int nk = plan_conv(tu, p, tile, coutPad, k);
     if (n_launches) *n_launches = p.k_slices > 1 ? 1 : nk;   // (the split-K reduce is not counted: include/yolact_hip.h)
     for (int i = 0; i < nk; ++i) {
@@ -2578,7 +2590,7 @@ static int build_profile_entries(yh_engine* h, int n, int with_tail, std::vector
         const int rc = fill_conv_params(h, o, n, &p, &tile);
         if (rc) return rc;
         const Panel& pn = h->panels[o.panel];
-        KLaunch k[2];
+        KLaunch k[3];
         const int nk = plan_conv(h->tune, p, tile, pn.coutPad, k);
         for (int j = 0; j < nk; ++j) { ProfEntry e{}; e.op = i; e.stage = -1; e.k = k[j]; e.is_conv = true; out->push_back(e); }
     }

@@ -82,6 +82,7 @@ struct ConvParams {
     int M;                // N*P*Q (rows this launch may write: m < M)
     int m_tile0;          // first row tile of this launch (two-phase launches: the tail starts past 0)
     int ch_tile0;         // first channel tile of this launch (channel-split launches), in units of this launch's tile
+    int ch_base;          // ... plus this many channels (a remainder launch whose first channel is no multiple of its tile: 256 on 96-channel tiles)
     // multi-level input (nlev > 0): the P*Q rows of an image are the cells of nlev pyramid levels laid end to
     // end (level l: rows lev_start[l].., a lev_h[l] x lev_w[l] image); taps stay inside their level
     int nlev, lev_start[5], lev_h[5], lev_w[5];
@@ -125,7 +126,8 @@ struct ConvParams {
 // (ids 4, 9-11, 14, 17, 25, 26 belonged to retired experiments: a 256x128 ring tile, the X3W2 ring, the shared-patch 3x3 kernel, rings of
 // four, the fp8 ring of three, register-fed 32 x 32 tiles - DESIGN.md §4, §12; tools/study/retired_r05_forms.patch)
 enum ConvTile { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x256 = 2, TILE_64x256_SMALLC = 3, TILE_128x256 = 5, TILE_256x256 = 6, TILE_128x128_S3 = 7, TILE_256x256_M16 = 8,
-                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24 };
+                TILE_128x128_M16 = 12, TILE_128x128_S3_M16 = 13, TILE_128x256_M16 = 15, TILE_64x64_S3 = 16, TILE_256x256_FP8 = 20, TILE_128x128_K1 = 21, TILE_64x256_K1 = 22, TILE_128x128_FP8 = 23, TILE_64x64_FP8 = 24,
+                TILE_96x128_K1 = 27 /* the streaming tile for a 96-channel remainder (the shared head's channels 256 .. 351): multi-level form only */ };
 int conv_tile_ch(ConvTile t);
 int conv_tile_m(ConvTile t);
 const char* conv_tile_symbol(ConvTile t);
