@@ -211,7 +211,9 @@ int yh_load_weights_device(yh_engine* h, const void* blob_dev, size_t nbytes);
  * scale s[c] is folded into the consumer's weights along K (t = w * s[c]) before their quantisation with one scale per
  * output channel (s_w = max |t| / 448), so the weights' E4M3 codes are (re)made whenever a tensor's scales are set; the
  * producer's epilogue multiplies by 1 / s[c] - a vector instead of a scalar, no extra pass. */
-/* Runs the f16 forward of the frames last set and sets the scales of every fp8 input tensor to max|x[.., c]| / 448. YH_ESTATE
+/* Runs the f16 forward of the frames last set and sets the scales of every fp8 input tensor to
+ * max(2 max|x[.., c]|, max|x| / 16) / 448 - twice the channel's own maximum on the calibration frames and never less than a sixteenth of
+ * the tensor's: headroom for frames the calibration has not seen (free in a floating-point code; round 5). YH_ESTATE
  * (and no scale changed) if that forward overflowed: a non-finite maximum would make every code of the tensor 0. */
 int yh_fp8_calibrate(yh_engine* h);
 /* The convolutions that read E4M3 operands, in execution order: layer name (DESIGN.md layer names: "l3b0_b", "p5",

@@ -32,6 +32,33 @@ def lib():
     return _LIB
 
 
+def usable_cores():
+    """Host cores this process may really use: the smallest of the machine's count, the affinity mask and the cgroup CPU quota. A
+    one-GPU box hands a job 16 of its 256 hardware threads: 256 OpenMP threads inside that quota ran the forward 40 x slower than
+    16 (bench.usable_cores, round 2) - and until round 5 that is what every oracle forward of the GPU test suite did."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 class NetCfg(C.Structure):
     _fields_ = [("backbone", C.c_int), ("input_size", C.c_int), ("num_classes", C.c_int)]
 
@@ -245,7 +272,7 @@ class Net:
         conf = np.empty((n, self.P, self.C), np.float32)
         mask = np.empty((n, self.P, 32), np.float32)
         proto = np.empty((n, self.hp, self.wp, 32), np.float32)
-        nt = nthreads or os.cpu_count() or 1
+        nt = nthreads or usable_cores()
         rc = lib().orc_net_forward(self.h, _p(rgb), n, 1 if f16 else 0, nt, _p(loc), _p(conf), _p(mask), _p(proto))
         assert rc == 0
         return loc, conf, mask, proto
@@ -271,7 +298,7 @@ def conv2d(x, w, bias, stride=1, pad=0, residual=None, act=0, f16=False, nthread
     res = None if residual is None else np.ascontiguousarray(residual, np.float32)
     lib().orc_conv2d(_p(x), n, h, ww, cin, _p(w), _p(bias), cout, kh, kw, stride, pad,
                      _p(res) if res is not None else None, act, 1 if f16 else 0,
-                     nthreads or os.cpu_count() or 1, _p(y))
+                     nthreads or usable_cores(), _p(y))
     return y
 
 

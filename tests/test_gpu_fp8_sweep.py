@@ -271,3 +271,99 @@ def test_fp8_detections_vs_fp8_oracle_above_the_head_noise(r101_fp8, oracle):
         print(f"frame {f}: fp8 engine vs f16 oracle: matched {acc['matched_class_and_prior']} of {acc['oracle_dets']} (engine {acc['engine_dets']}), mask IoU matched {acc['mask_iou_matched']}, all {acc['mask_iou_all']}")
         if real:
             assert acc["oracle_dets"] >= 5 and acc["unmatched_oracle"] <= 1 and acc["unmatched_engine"] <= 2 and acc["mask_iou_matched"] >= 0.70, acc
+
+
+def _fp8_layer_map(eng):
+    lay = {}
+    for name, sc in eng.fp8_channel_scales():
+        for nm in ([f"{name}{l}" for l in range(5)] if name == "head_t" else [name]):
+            lay[nm] = sc
+    return lay
+
+
+def test_fp8_share_of_eight_frames_pooled_against_its_checker(built, oracle):
+    """configs[4]'s own per-GPU share - YOLACT-700 R101, fp8 precision, EIGHT frames - at detection level, pooled the way the
+    driver-timed bench line pools it (`configs4.accuracy.*_all_frames`: bench.fp8_vs_oracles / pool_accuracy): the fp8 engine
+    against the oracle's fp8 forward mode with the engine's own calibrated scales, over all eight frames (seven noise frames and the
+    reference's test image). Round 4's test looked at two frames; one noise frame is a handful of decisions near the 0.05
+    threshold. Floors just under what is measured - on these eight frames 171 matched of the checker's 207 (0.83; per frame 21 of 26 ...
+    27 of 30), matched-pair mask IoU 0.75, 229 engine detections (round 5's calibration: twice the channel maximum, at least a sixteenth
+    of the tensor's; with round 4's bare channel maxima: 179 of 232 = 0.77, 0.70; with the floor at an eighth: 168 of 219 = 0.77, 0.74 -
+    the spread of one scheme change IS the noise of these figures); the driver's line of round 4, on the bench's own frames: 188 of 235
+    (0.80), 0.66 -:
+      matched fraction of the checker's detections >= 0.74, detection-weighted mean of the matched-pair mask IoU >= 0.62,
+      the engine's own detection count within 15 % of the checker's (spurious detections are decisions too)."""
+    import bench
+    import yolact_amd as ya
+    n = 8
+    eng = ya.Engine(input_size=S7, backbone=101, max_batch=n, use_graph=True, precision=ya.PRECISION_FP8)
+    blob = eng.generate_weights(seed=1)
+    eng.load_weights(blob)
+    frames = np.random.default_rng(8).integers(0, 256, (n, S7, S7, 3), dtype=np.uint8)
+    balls = bench.acceptance_frame(S7)
+    if balls is not None:
+        frames[n - 1] = balls[0]
+    eng.set_input(frames)
+    eng.fp8_calibrate()
+    eng.evaluate()
+    names = [p["name"] for p in eng.profile(with_tail=True, reps=1)]
+    assert sum(nm.startswith("bneck_xn_f16:") for nm in names) == 21            # the share's own launch plan (242 tiles per layer-3 launch)
+    net = oracle.Net(101, S7, 81, blob=blob)
+    pri = net.priors()
+    net.set_fp8(_fp8_layer_map(eng))
+    per = []
+    for f in range(n):
+        h8 = net.forward(frames[f:f + 1], f16=True)
+        per.append(bench.accuracy_vs_oracle(eng.detections(f), oracle.detect(h8[0][0], h8[1][0], h8[2][0], h8[3][0], pri)))
+    net.set_fp8(None)
+    pooled = bench.pool_accuracy(per)
+    print("pooled over 8 frames, fp8 engine vs fp8-mode checker:", {k: v for k, v in pooled.items() if not k.endswith("_per_frame")})
+    print("per frame matched / checker / engine:", [(r["matched_class_and_prior"], r["oracle_dets"], r["engine_dets"]) for r in per])
+    assert pooled["oracle_dets"] >= 100 and pooled["matched_fraction_of_oracle"] >= 0.74, pooled
+    assert pooled["mask_iou_matched_mean"] >= 0.62, pooled
+    assert abs(pooled["engine_dets"] - pooled["oracle_dets"]) <= 0.15 * pooled["oracle_dets"], pooled
+    eng.close()
+
+
+def test_fp8_channel_scales_calibrated_on_other_frames(built, oracle):
+    """the per-input-channel activation scales (the default since round 4) are maxima of the calibration frames with no
+    headroom - a channel that is quiet there and active later saturates at 448 s[c], a risk one scale per tensor does not have - and
+    every accuracy figure of the suite calibrated and evaluated on the same frames. Held-out check, both directions: calibrate on
+    noise frames and evaluate on the reference's test image at 700 x 700, calibrate on that image and evaluate on a noise frame;
+    against the F16 oracle, the per-channel scheme must do no worse than one scale per tensor calibrated the same way (matched
+    detections, up to two - one noise frame's list is some thirty decisions near the threshold; matched-pair mask IoU, up to 0.05).
+    Measured with round 4's scales (bare channel maxima): calibrated on the test image, evaluated on noise 21 of 31 matched, IoU 0.63,
+    against 25 and 0.74 for one scale per tensor - the risk was real. With round 5's headroom (twice the channel maximum, at least a
+    sixteenth of the tensor's): 23 of 31, 0.77; the other direction 8 of 8, 0.76 (per tensor: 8 of 8, 0.80).
+    Nothing in the reference pins E4M3: parity unpinned."""
+    import bench
+    import yolact_amd as ya
+    balls = bench.acceptance_frame(S7)
+    if balls is None:
+        pytest.skip("tests/golden/frc_balls.png is missing")
+    noise = np.random.default_rng(23).integers(0, 256, (3, S7, S7, 3), dtype=np.uint8)
+    net = oracle.Net(101, S7, 81, seed=1)
+    pri = net.priors()
+
+    def f16_dets(fr):
+        h = net.forward(fr, f16=True)
+        return oracle.detect(h[0][0], h[1][0], h[2][0], h[3][0], pri)
+    want = {"balls": f16_dets(balls[:1]), "noise": f16_dets(noise[:1])}
+    res = {}
+    for per_tensor in (False, True):
+        eng = ya.Engine(input_size=S7, backbone=101, max_batch=3, use_graph=True, precision=ya.PRECISION_FP8, fp8_per_tensor=per_tensor)
+        eng.load_weights(eng.generate_weights(seed=1))
+        for calib, ev, key in ((noise, balls[:1], "balls"), (np.repeat(balls[:1], 3, 0), noise[:1], "noise")):
+            eng.set_input(calib)
+            eng.fp8_calibrate()
+            eng.set_input(ev)
+            eng.evaluate()
+            res[(per_tensor, key)] = bench.accuracy_vs_oracle(eng.detections(0), want[key])
+        eng.close()
+    for key in ("balls", "noise"):
+        ch, pt = res[(False, key)], res[(True, key)]
+        print(f"evaluated on {key}, calibrated on the other set: per channel matched {ch['matched_class_and_prior']} of {ch['oracle_dets']} (engine {ch['engine_dets']}), "
+              f"IoU matched {ch['mask_iou_matched']}; per tensor matched {pt['matched_class_and_prior']} (engine {pt['engine_dets']}), IoU matched {pt['mask_iou_matched']}")
+        assert ch["matched_class_and_prior"] >= pt["matched_class_and_prior"] - 2, (key, ch, pt)
+        assert (ch["mask_iou_matched"] or 0) >= (pt["mask_iou_matched"] or 0) - 0.05, (key, ch, pt)
+        assert ch["matched_class_and_prior"] >= 0.6 * ch["oracle_dets"], (key, ch)
