@@ -581,12 +581,8 @@ __global__ __launch_bounds__(512, 1) void bneck_xn_f16(const BneckParams p) {
                 const half8 o = *(const half8*)(lds + kt * (TM * 128) + (rb + 32 * d) * 128 + pc * 16);
                 if (p.a_next) *(half8*)(p.a_next + (long long)m * PL + kt * 64 + lc * 8) = o;
                 if (p.a_next8) {   // fp8 precision: a' feeds an fp8 convolution (quantised from the f16-rounded value, as conv_igemm's epilogue)
-                    unsigned lo = 0, hi = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
-                        hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
-                    }
+                    const unsigned lo = e4m3_pack4((float)o[0] * inv0[0], (float)o[1] * inv0[1], (float)o[2] * inv0[2], (float)o[3] * inv0[3]);
+                    const unsigned hi = e4m3_pack4((float)o[4] * inv1[0], (float)o[5] * inv1[1], (float)o[6] * inv1[2], (float)o[7] * inv1[3]);
                     *(uint2*)(p.a_next8 + (long long)m * PL + kt * 64 + lc * 8) = make_uint2(lo, hi);
                 }
             }

@@ -634,12 +634,8 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                     if (p.y) *(half8*)(p.y + yo) = o;
                     if (p.y8) {   // fp8 precision: this tensor feeds an fp8 convolution (quantised from the f16-rounded value)
-                        unsigned lo = 0, hi = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            lo |= e4m3_code((float)o[e] * inv0[e]) << (8 * e);
-                            hi |= e4m3_code((float)o[4 + e] * inv1[e]) << (8 * e);
-                        }
+                        const unsigned lo = e4m3_pack4((float)o[0] * inv0[0], (float)o[1] * inv0[1], (float)o[2] * inv0[2], (float)o[3] * inv0[3]);
+                        const unsigned hi = e4m3_pack4((float)o[4] * inv1[0], (float)o[5] * inv1[1], (float)o[6] * inv1[2], (float)o[7] * inv1[3]);
                         *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
                     }
                 }
@@ -882,9 +878,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16(const ConvParams p) {
     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
     if (p.y) *(half8*)(p.y + yo) = o;
     if (p.y8) {
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * p.y8_inv[ch + e]) << (8 * e); hi |= e4m3_code((float)o[4 + e] * p.y8_inv[ch + 4 + e]) << (8 * e); }
+        const float* iv = p.y8_inv + ch;
+        const unsigned lo = e4m3_pack4((float)o[0] * iv[0], (float)o[1] * iv[1], (float)o[2] * iv[2], (float)o[3] * iv[3]);
+        const unsigned hi = e4m3_pack4((float)o[4] * iv[4], (float)o[5] * iv[5], (float)o[6] * iv[6], (float)o[7] * iv[7]);
         *(uint2*)(p.y8 + yo) = make_uint2(lo, hi);
     }
 }

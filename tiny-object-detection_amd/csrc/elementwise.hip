@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x
     const int c = c8 * 8;
     half8 p00[BIL_ROWS], p01[BIL_ROWS], p10[BIL_ROWS], p11[BIL_ROWS];
     float ly[BIL_ROWS];
+    float inv8[8];   // fp8 output: this lane's eight reciprocal channel scales, loaded once (not behind every row's store)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) inv8[e] = y8 ? y8_inv[cg * 8 + e] : 1.0f;
 #pragma unroll
     for (int r = 0; r < BIL_ROWS; ++r) {
         const int oy = oy0 + r < ho ? oy0 + r : ho - 1;   // (rows past the end recompute the last row and are not stored)
@@ -104,9 +107,8 @@ __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x
         const long long yo = b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8;
         if (y) *(half8*)(y + yo) = o;
         if (y8) {   // fp8 precision: the consumer is an fp8 convolution (quantised from the f16-rounded value, one scale per channel)
-            unsigned lo = 0, hi = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { lo |= e4m3_code((float)o[e] * y8_inv[cg * 8 + e]) << (8 * e); hi |= e4m3_code((float)o[4 + e] * y8_inv[cg * 8 + 4 + e]) << (8 * e); }
+            const unsigned lo = e4m3_pack4((float)o[0] * inv8[0], (float)o[1] * inv8[1], (float)o[2] * inv8[2], (float)o[3] * inv8[3]);
+            const unsigned hi = e4m3_pack4((float)o[4] * inv8[4], (float)o[5] * inv8[5], (float)o[6] * inv8[6], (float)o[7] * inv8[7]);
             *(uint2*)(y8 + yo) = make_uint2(lo, hi);
         }
     }

@@ -205,6 +205,18 @@ __device__ __forceinline__ unsigned e4m3_code(float v) {
     const float c = fminf(fmaxf(v, -448.0f), 448.0f);
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.0f, 0, false) & 0xFFu;
 }
+// four codes as one dword (a in the low byte): the same function as four e4m3_code calls, with the packed conversion - two values per
+// v_cvt_pk_fp8_f32, clamped by v_med3_f32 - instead of a convert, a mask, a shift and an or per value; NaNs (never seen on a calibrated
+// network: the calibration refuses a forward that overflowed) take the element-wise path so that the codes stay identical
+__device__ __forceinline__ unsigned e4m3_pack4(float a, float b, float c, float d) {
+    if (__builtin_expect(a != a || b != b || c != c || d != d, 0))
+        return e4m3_code(a) | (e4m3_code(b) << 8) | (e4m3_code(c) << 16) | (e4m3_code(d) << 24);
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
 // heads [n][cells][ldh] f16 -> loc/conf/mask/cells split as f32 (output reads only)
 hipError_t launch_split_heads(const half_t* heads, int n, int cells, int ldh, int C, float* loc,
                               float* conf, float* mask, hipStream_t s);
