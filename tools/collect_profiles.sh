@@ -62,4 +62,14 @@ echo "[6/6] SQ counters"
   done
 } > $OUT/${TAG}_pmc_kernels.txt
 rm -rf $OUT/stats $OUT/stats4 $OUT/pmcF $OUT/pmcW $OUT/tfl0 $OUT/tfl1 $OUT/tl3 $OUT/tl2; find $OUT -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
+# Round 5: the GPU test run of THIS tree is part of the collection, green or not (tests/conftest.py arms faulthandler:
+# a crash leaves every thread's Python stack in it), and every log of the collection that is not green is kept under a name that says so -
+# round 4's host segfault was lost because only the green re-run's log survived. Copy ${TAG}_* (all of them) into profiles/.
+( cd $R && python3 -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.txt 2>&1; echo "exit code $?" >> $OUT/${TAG}_pytest_gpu.txt ) || true
+for f in $OUT/*.log $OUT/*.err $OUT/${TAG}_pytest_gpu.txt; do
+  [ -f "$f" ] || continue
+  if grep -q -E "Traceback|Segmentation fault|Fatal Python error|Memory access fault|core dumped|Aborted|FAILED|exit code [1-9]" "$f"; then
+    cp "$f" "$OUT/${TAG}_NONGREEN_$(basename "$f").txt"
+  fi
+done
 echo done
