@@ -93,3 +93,21 @@ def test_product_never_imports_oracle():
         if f.endswith((".py", ".sh")):
             txt = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
             assert not re.search(r"import\s+(oracle|tfl_oracle)|liboracle|tfl_oracle as", txt), f
+
+
+def test_standin_librccl_builds_and_exports_what_the_library_binds(tmp_path):
+    """tests/rccl_standin/librccl_standin.c (TEST infrastructure: the stand-in that lets a one-GPU box execute the n > 1 collective
+    code, tests/test_gpu_rccl_standin.py) compiles with gcc against the ROCm headers and exports exactly the eight entry points
+    csrc/engine.hip binds by name - and the product never names it: libyolact_hip.so still asks the loader for librccl.so.1."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "rccl_standin", "librccl_standin.c")
+    so = tmp_path / "librccl.so.1"
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-I/opt/rocm/include", "-o", str(so), src, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    out = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
+    have = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    want = {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclBroadcast", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"}
+    assert want <= have, want - have
+    eng = open(os.path.join(ROOT, "tiny-object-detection_amd", "csrc", "engine.hip")).read()
+    for sym in want:
+        assert f'sym("{sym}")' in eng, sym
+    assert "rccl_standin" not in eng.replace("tests/rccl_standin", "") and '"librccl.so.1"' in eng

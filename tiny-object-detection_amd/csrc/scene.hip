@@ -83,20 +83,20 @@ __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t*
 //           x - L .. x + L - 1 with L <= 20: the strip's taps land in map columns [c0 - 20, c0 + 36) - the LDS image's 56 columns;
 //   band    map rows [r0, r0 + 64): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
 //           of each bump that fall into its own band; bands make the grid ~W/16 x H/64 = 320 workgroups at 640 x 480 and keep
-//           the image at 14 KB, several workgroups per CU.
-// A wave takes pixel rows y = wave, wave + 8, ...: lanes 0-15 compute the row's 16 pixels (the shader's arithmetic, one IEEE
-// operation per operator), then the wave stamps the row's bump pixels one at a time (ballot + readlane: wave-uniform target),
+//           the image at 21 KB, several workgroups per CU.
+// A wave takes four pixel rows at a time: its 64 lanes compute the 4 x 16 pixels (the shader's arithmetic, one IEEE
+// operation per operator), then the wave stamps the bump pixels one at a time (ballot + readlane: wave-uniform target),
 // lane t owning taps t, t + 64, ... of the bump. The tap HEIGHTS sit in registers: a terrain tap depends on the pixel's row only
 // (pt_cloud.comp:116), so the row's 400-entry table is loaded once per row (7 coalesced loads, only if some pixel of the row hits
 // the band) and serves its 16 pixels; the robot table (1 600 entries, a constant) is loaded once per workgroup (25 registers). The
-// stamping loop therefore has no memory read: per tap a range test and one ds_max_u32 (row pitch 57: odd). A tap of height 0
+// stamping loop therefore has no memory read: per tap a range test and one ds_max_u32 (row pitch 84 words). A tap of height 0
 // changes nothing and is not issued. (First version of this kernel, a wave per pixel with the table read from global memory inside
 // the tap loop: 0.56-0.65 ms per frame against 2.0-2.3 for the global-atomic form; it waited for one L2 round trip per 64 taps.)
 // Ball pixels add their position to 64-bit sums in LDS (band 0 only: once per pixel), flushed once per workgroup.
 #define SC_CW 16
 #define SC_BH 64
 #define SC_HALO 20
-#define SC_LDW (SC_CW + 2 * SC_HALO + 1)
+#define SC_LDW 84   // 56 columns used; 84 = 64 + 20: a wave's 3.2 consecutive tap rows of a terrain bump fall on 64 different banks
 #define SC_TT (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM)   // 400 taps
 #define SC_RT (4 * SC_BOT_NORM * SC_BOT_NORM)           // 1600 taps
 #define SC_TK ((SC_TT + 63) / 64)                       // 7 taps per lane
@@ -116,10 +116,15 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
     const int cw = min(SC_CW, p.W - c0);
     const int band_lo = max(r0, 1), band_hi = min(r0 + SC_BH, p.H - 1);   // rows y with 0 < y < H - 1 inside the band
     const int ibase = -r0 * SC_LDW - (c0 - SC_HALO);                       // img[ibase + y * SC_LDW + x] = the cell of map (x, y)
-    for (int y = wave; y < p.H; y += 8) {
+    // FOUR pixel rows per wave and iteration (lane = 16 (row in the group) + column): the depth / class loads of 64 pixels are one
+    // latency, not four, and the four rows' terrain tables are requested together before the first stamp (the first version of this loop
+    // took one row at a time: 60 exposed round trips per wave on a grid of ~1.25 workgroups per CU)
+    const int lr = lane >> 4, lc = lane & 15;
+    for (int y4 = 4 * wave; y4 < p.H; y4 += 32) {
+        const int y = y4 + lr;
         int nx = 0, ny = 0, L = 0;
-        if (lane < cw) {
-            const int x = c0 + lane;
+        if (lc < cw && y < p.H) {
+            const int x = c0 + lc;
             const size_t i = (size_t)y * p.W + x;
             const float ty = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_YFOV, (float)y), 2.0f), (float)p.H);
             const float tx = __fdiv_rn(__fmul_rn(__fmul_rn(SC_TAN_HALF_XFOV, (float)x), 2.0f), (float)p.W);
@@ -147,22 +152,35 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
             } else L = SC_BOT_NORM;
         }
         const bool hit = L > 0 && max(ny - L, band_lo) < min(ny + L, band_hi);   // this lane's bump meets the band
-        unsigned long long todo_t = __ballot(hit && L == SC_TERRAIN_NORM), todo_r = __ballot(hit && L == SC_BOT_NORM);
-        if (todo_t) {
-            uint32_t tt[SC_TK];   // the terrain bump of THIS row, this lane's taps
-            const uint32_t* trow = p.terrain_tab + (size_t)y * SC_TT;
+        const unsigned long long hit_t = __ballot(hit && L == SC_TERRAIN_NORM);
+        unsigned long long todo_r = __ballot(hit && L == SC_BOT_NORM);
+        if (hit_t) {
+            uint32_t tt[4][SC_TK];   // the terrain bumps of the four rows, this lane's taps (a row without a hit is not fetched)
 #pragma unroll
-            for (int k = 0; k < SC_TK; ++k) tt[k] = lane + 64 * k < SC_TT ? trow[lane + 64 * k] : 0u;
-            while (todo_t) {
-                const int j = __ffsll((long long)todo_t) - 1;
-                todo_t &= todo_t - 1;
-                const int x0 = __builtin_amdgcn_readlane(nx, j) - SC_TERRAIN_NORM, y0 = __builtin_amdgcn_readlane(ny, j) - SC_TERRAIN_NORM;
+            for (int r = 0; r < 4; ++r) {
+                if ((hit_t >> (16 * r)) & 0xFFFFull) {
+                    const uint32_t* trow = p.terrain_tab + (size_t)(y4 + r) * SC_TT;
 #pragma unroll
-                for (int k = 0; k < SC_TK; ++k) {
-                    const int t = lane + 64 * k, ly = t / (2 * SC_TERRAIN_NORM), lx = t - ly * (2 * SC_TERRAIN_NORM);
-                    const int yy = y0 + ly, xx = x0 + lx;
-                    if (tt[k] && yy >= band_lo && yy < band_hi && xx > 0 && xx < p.W - 1)
-                        __hip_atomic_fetch_max(&img[ibase + yy * SC_LDW + xx], tt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int k = 0; k < SC_TK; ++k) tt[r][k] = lane + 64 * k < SC_TT ? trow[lane + 64 * k] : 0u;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < SC_TK; ++k) tt[r][k] = 0u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned long long todo_t = hit_t & (0xFFFFull << (16 * r));
+                while (todo_t) {
+                    const int j = __ffsll((long long)todo_t) - 1;
+                    todo_t &= todo_t - 1;
+                    const int x0 = __builtin_amdgcn_readlane(nx, j) - SC_TERRAIN_NORM, y0 = __builtin_amdgcn_readlane(ny, j) - SC_TERRAIN_NORM;
+#pragma unroll
+                    for (int k = 0; k < SC_TK; ++k) {
+                        const int t = lane + 64 * k, ly = t / (2 * SC_TERRAIN_NORM), lx = t - ly * (2 * SC_TERRAIN_NORM);
+                        const int yy = y0 + ly, xx = x0 + lx;
+                        if (tt[r][k] && yy >= band_lo && yy < band_hi && xx > 0 && xx < p.W - 1)
+                            __hip_atomic_fetch_max(&img[ibase + yy * SC_LDW + xx], tt[r][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
