@@ -672,9 +672,14 @@ __global__ __launch_bounds__(WCH * WM * 64, 2) void conv_igemm_f16(const ConvPar
 // groups, so a group never wraps over a row; with 42 patch columns (row pitch 336 B) and a 184-byte staging pitch every B
 // fragment read and every staging write is conflict free and the pool's reads are 2-way (before: 289 pixels taken 16 at a
 // time, pitches 40 / 144 - 1.8-way, 1.9-way and 3-way; SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).
-__global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) {
+__global__ __launch_bounds__(512, 4) void stem_pool_f16(const StemPoolParams p) {   // (4 waves per SIMD = two workgroups per CU: at most 128 VGPRs)
     __shared__ __attribute__((aligned(16))) char patch[SP_PR * SP_PC * 8];
     __shared__ __attribute__((aligned(16))) char stage[SP_NPX * SP_SS];
+    // Round 5: what a lane needs to know about pixel group mt - where its B fragment starts in the patch, where its stem pixel sits in the
+    // staging image, whether it holds a pixel at all - depends on (mt, lane) only, not on the tile: tabulated once per workgroup (9.7 KB)
+    // instead of ~17 vector instructions of selects and multiplies per group and tile. word 0: patch byte offset | mi << 16 | mj << 21 |
+    // in_tile << 26; word 1: staging byte offset of the pixel (+ this lane's channel quad).
+    __shared__ uint2 gtab[(SP_ST + 2) * 64];
     typedef float accv __attribute__((ext_vector_type(4)));
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lh = lane >> 4;
@@ -685,12 +690,21 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 7; ++r) a[ct][r] = *(const half8*)(p.w + ((ct0 + ct) * 16 + l15) * 256 + r * 32 + lh * 8);
-    f32x4 bias4[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) bias4[ct] = *(const f32x4*)(p.bias + (ct0 + ct) * 16 + 4 * lh);
+    // (the 64 biases live in LDS, not in 8 registers per lane: with the group table's two words the kernel stood at 130 VGPRs - one
+    // workgroup per CU instead of two; a group's accumulators start from two ds_read_b128 that land under its first B-fragment read)
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    if (tid < 64) bias_s[tid] = p.bias[tid];
 
+    for (int e = tid; e < (SP_ST + 2) * 64; e += 512) {
+        const int mt = e >> 6, ln = e & 63, c15 = ln & 15, q = ln >> 4;
+        const int in_t = mt < SP_ST + 1 || c15 == 0;
+        const int mi = mt < SP_ST ? mt : (mt == SP_ST ? c15 : SP_ST - 1), mj = mt < SP_ST ? c15 : SP_ST - 1;
+        gtab[e] = make_uint2((unsigned)(((2 * mi) * SP_PC + 2 * mj + 2 * q) * 8) | ((unsigned)mi << 16) | ((unsigned)mj << 21) | ((unsigned)in_t << 26),
+                             (unsigned)((mi * SP_ST + mj) * SP_SS + 4 * q * 2));
+    }
     const int tiles_img = p.tiles_y * p.tiles_x, total = p.n * tiles_img;
     constexpr int NCH = SP_PR * (SP_PC / 2), NLD = (NCH + 511) / 512;   // 16-byte patch chunks, per-thread slots
+
     half8 nv[NLD];
     unsigned raw[NLD][2];   // rgb form: two pixels' raw bytes (c0 | c1 << 8 | c2 << 16 | valid << 24) - converted in store_patch
     // the next tile's patch travels through registers: loads are issued before this tile's MFMA
@@ -700,6 +714,25 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
         const int b = tile / tiles_img, rem = tile - b * tiles_img;
         const int by0 = 4 * ((rem / p.tiles_x) * SP_PT) - 2, bx0 = 4 * ((rem % p.tiles_x) * SP_PT) - 2;   // even column
         const half_t* img = p.x + (long long)b * p.x_img_stride;
+        if (p.rgb && by0 - 3 >= 0 && by0 - 3 + SP_PR <= p.S && bx0 - 3 >= 0 && bx0 - 3 + 40 <= p.S) {
+            // INTERIOR tile (a wave-uniform test: 4 of 5 tiles at 550 x 550): the whole 39 x 40-pixel patch lies inside the image, so no
+            // pixel needs a bounds test and a pixel pair is six consecutive bytes from a scalar base + a per-thread constant - one dword and
+            // one short (unaligned: the target's global loads allow it) instead of four byte / short loads behind two branches
+            struct __attribute__((packed, aligned(1))) U32 { unsigned v; };
+            struct __attribute__((packed, aligned(1))) U16 { unsigned short v; };
+            const uint8_t* base = p.rgb + (((long long)b * p.S + (by0 - 3)) * p.S + (bx0 - 3)) * 3;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
+                raw[k][0] = raw[k][1] = 0u;
+                if (i < NCH && cp < 20) {
+                    const uint8_t* q = base + (row * p.S + 2 * cp) * 3;
+                    raw[k][0] = ((const U32*)q)->v;          // (untouched until store_patch: the loads land under this tile's MFMA phase)
+                    raw[k][1] = ((const U16*)(q + 4))->v | 0x80000000u;   // bit 31: the slot holds six packed bytes, not two flagged pixels
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
@@ -732,6 +765,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 512 * k, row = i / (SP_PC / 2), cp = i - row * (SP_PC / 2);
             if (p.rgb) {
+                if (raw[k][1] & 0x80000000u) {   // an interior tile's slot: bytes 0-3 | bytes 4-5 -> two flagged pixels
+                    const unsigned lo = raw[k][0], hi = raw[k][1] & 0xFFFFu;
+                    raw[k][0] = (lo & 0xFFFFFFu) | (1u << 24);
+                    raw[k][1] = (lo >> 24) | (hi << 8) | (1u << 24);
+                }
 #pragma unroll
                 for (int px = 0; px < 2; ++px) {
                     const bool ok = (raw[k][px] >> 24) != 0u;
@@ -753,39 +791,57 @@ __global__ __launch_bounds__(512, 2) void stem_pool_f16(const StemPoolParams p) 
         const int next = tile + gridDim.x;
         __syncthreads();   // patch visible; the previous tile's pool phase is done with the staging image
         if (next < total) fetch_patch(next);
+        // (a tile whose 17 x 17 stem pixels all lie inside the stem image - every tile off the image's border - needs no per-pixel range test)
+        const bool inner = !p.stem && py0 > 0 && px0 > 0 && 2 * py0 + 15 < p.SO && 2 * px0 + 15 < p.SO;
         for (int mt = wp; mt < SP_ST + 2; mt += 4) {
-            // group mt < 17: stem row mt, columns 0 .. 15; group 17: column 16, rows 0 .. 15; group 18: pixel (16, 16)
-            const bool in_tile = mt < SP_ST + 1 || l15 == 0;
-            const int mi = mt < SP_ST ? mt : (mt == SP_ST ? l15 : SP_ST - 1), mj = mt < SP_ST ? l15 : SP_ST - 1;
-            const int m = mi * SP_ST + mj;
+            // group mt < 17: stem row mt, columns 0 .. 15; group 17: column 16, rows 0 .. 15; group 18: pixel (16, 16) - gtab
+            const uint2 g = gtab[mt * 64 + lane];
+            const bool in_tile = (g.x >> 26) & 1u;
             accv acc[2];   // start from the bias: one rounding fewer than (sum) + bias, and no separate add
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[ct][e] = bias4[ct][e];
-            const char* bp = patch + ((2 * mi) * SP_PC + 2 * mj + 2 * lh) * 8;
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = *(const accv*)(bias_s + (ct0 + ct) * 16 + 4 * lh);
+            const char* bp = patch + (g.x & 0xFFFFu);
+            // (two fragments in flight: row r + 1 is requested before row r's MFMAs - written as a rotation of two named registers because
+            // the compiler, left to itself at 127 VGPRs, waited for every read right behind its issue)
+            half8 bf0 = *(const half8*)(bp), bf1 = *(const half8*)(bp + SP_PC * 8);
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
-                const half8 bf = *(const half8*)(bp + r * SP_PC * 8);
+                const half8 bf = (r & 1) ? bf1 : bf0;
+                if (r + 2 < 7) { if (r & 1) bf1 = *(const half8*)(bp + (r + 2) * SP_PC * 8); else bf0 = *(const half8*)(bp + (r + 2) * SP_PC * 8); }
+                __builtin_amdgcn_sched_barrier(0);   // (the request stays in front of this row's MFMAs)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma_f16<16>(a[ct][r], bf, acc[ct]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const int sy = 2 * py0 - 1 + mi, sx = 2 * px0 - 1 + mj;
-            const bool ok = in_tile && (unsigned)sy < (unsigned)p.SO && (unsigned)sx < (unsigned)p.SO;
-            if (in_tile) {
-                half4 zero4;
+            half4 zero4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) zero4[e] = (half_t)0.0f;
+            for (int e = 0; e < 4; ++e) zero4[e] = (half_t)0.0f;
+            char* const sp = stage + g.y + ct0 * 32;
+            if (inner) {
+                if (in_tile) {
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    // ReLU after the f16 rounding (rounding is monotonic and keeps 0): two packed ops
-                    half4 o = __builtin_convertvector(acc[ct], half4);
-                    o = __builtin_elementwise_max(o, zero4);
-                    o = ok ? o : zero4;
-                    *(half4*)(stage + m * SP_SS + ((ct0 + ct) * 16 + 4 * lh) * 2) = o;
-                    // test hook: each stem pixel is owned by the tile that holds it off the halo row / column
-                    if (p.stem && ok && mi >= 1 && mj >= 1)
-                        *(half4*)(p.stem + (long long)b * p.stem_img_stride + ((long long)sy * p.SO + sx) * 64 + (ct0 + ct) * 16 + 4 * lh) = o;
+                    for (int ct = 0; ct < 2; ++ct) {
+                        // ReLU after the f16 rounding (rounding is monotonic and keeps 0): two packed ops
+                        half4 o = __builtin_convertvector(acc[ct], half4);
+                        o = __builtin_elementwise_max(o, zero4);
+                        *(half4*)(sp + ct * 32) = o;
+                    }
+                }
+            } else {
+                const int mi = (int)((g.x >> 16) & 31u), mj = (int)((g.x >> 21) & 31u);
+                const int sy = 2 * py0 - 1 + mi, sx = 2 * px0 - 1 + mj;
+                const bool ok = in_tile && (unsigned)sy < (unsigned)p.SO && (unsigned)sx < (unsigned)p.SO;
+                if (in_tile) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        half4 o = __builtin_convertvector(acc[ct], half4);
+                        o = __builtin_elementwise_max(o, zero4);
+                        o = ok ? o : zero4;
+                        *(half4*)(sp + ct * 32) = o;
+                        // test hook: each stem pixel is owned by the tile that holds it off the halo row / column
+                        if (p.stem && ok && mi >= 1 && mj >= 1)
+                            *(half4*)(p.stem + (long long)b * p.stem_img_stride + ((long long)sy * p.SO + sx) * 64 + (ct0 + ct) * 16 + 4 * lh) = o;
+                    }
                 }
             }
         }
