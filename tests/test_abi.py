@@ -6,10 +6,15 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "yolact_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(yh_[a-z0-9_]+)\s*\(", src)))
+def _declared(headers=("yolact_hip.h", "yolact_hip_debug.h")):
+    """Every yh_* function the headers under include/ declare: the drop-in boundary (yolact_hip.h) and the measurement / study / test
+    surface (yolact_hip_debug.h)."""
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(yh_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
 
 
 def test_every_declared_symbol_is_exported_and_bound(built):
@@ -43,7 +48,7 @@ def test_struct_layouts_match_the_header(built, tmp_path):
     from yolact_amd import capi
     src = tmp_path / "layout.c"
     fields = ["tune.plan_cus", "tune.tfl_graph", "precision", "debug_tensors", "conf_thresh"]
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yolact_hip.h"\nint main(void) {\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yolact_hip_debug.h"\nint main(void) {\n'
                    'printf("%zu %zu %zu %zu", sizeof(yh_config), sizeof(yh_tuning), sizeof(yh_detection), sizeof(yh_tensor_info));\n'
                    + "".join(f'printf(" %zu", offsetof(yh_config, {f}));\n' for f in fields) + "return 0; }\n")
     exe = tmp_path / "layout"
@@ -111,3 +116,21 @@ def test_standin_librccl_builds_and_exports_what_the_library_binds(tmp_path):
     for sym in want:
         assert f'sym("{sym}")' in eng, sym
     assert "rccl_standin" not in eng.replace("tests/rccl_standin", "") and '"librccl.so.1"' in eng
+
+
+def test_the_host_facing_header_stands_alone_and_carries_no_lab_notebook(tmp_path):
+    """include/yolact_hip.h - what a maintainer binds - compiles on its own as C, keeps yh_tuning opaque (32 ints: the
+    same size as the named struct of yolact_hip_debug.h), and declares no measurement, study, test or single-op entry point; the C++ host
+    mirror includes only it."""
+    import subprocess
+    pub = open(os.path.join(ROOT, "include", "yolact_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", pub, flags=re.S)
+    assert "int32_t knob[32]" in code and "plan_cus" not in code and "yolact_hip_debug.h" not in code
+    for name in _declared(("yolact_hip.h",)):
+        assert not name.startswith(("yh_debug_", "yh_op_", "yh_profile_")) and name not in ("yh_set_tuning", "yh_get_tuning", "yh_time_steps", "yh_scene_time", "yh_tfl_create_tuned"), name
+    src = tmp_path / "pub.c"
+    src.write_text('#include "yolact_hip.h"\ntypedef char ok[sizeof(yh_tuning) == 128 ? 1 : -1];\nint main(void) { yh_config c; yh_default_config(&c); return c.abi_version == YH_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    for f in ("yolact.hpp", "yolact.cpp", "yolact_demo.cpp"):
+        txt = open(os.path.join(ROOT, "tiny-object-detection_amd", "host", f)).read()
+        assert "yolact_hip_debug.h" not in txt, f

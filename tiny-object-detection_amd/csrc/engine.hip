@@ -130,7 +130,7 @@ uint16_t f32_to_f16_bits(float f) {  // round to nearest even, IEEE binary16
 
 }  // namespace
 
-// The handle's tuning with every default resolved (include/yolact_hip.h: yh_tuning; -1 = default there).
+// The handle's tuning with every default resolved (include/yolact_hip_debug.h: yh_tuning; -1 = default there).
 struct Tune {
     int plan_cus, mfma16, t128x256_m16, small16, bigk, tailsplit, chsplit, k1tile, k1_maxk, splitk_minsteps, t64, t64_maxb,
         t64_minsteps, stemfuse, prefuse, headmerge, upfuse, k1_generic, ablate, op_tile, op_kslices, tailfork, dsfuse, headfork_maxb, protofuse, k1_min1, k1_min3, chain;

@@ -6,7 +6,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/yolact_hip.h"
+#include "../../include/yolact_hip_debug.h"   // (the public header + the named tuning fields, measurement / test entry points)
 
 namespace yh {
 
