@@ -42,6 +42,7 @@ struct SceneParams {
     const uint32_t* frame;        // [H][W] packed pixels as classify leaves them
     int frame_mode;               // with `frame`: 0 = low 16 bits as src/scene.rs:93 reads them, 1 = class bits 31-24, id bits 23-16
     int W, H, mode;
+    int band_h;                   // map rows per workgroup of scene_cloud_strips (<= SC_BH; chosen so that the grid is one round of the chip)
     uint32_t* map;                // [H][W]
     float4 *world, *conn0, *conn1;
     long long* ball_acc;          // [3][100]: sum x, sum y, count
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t*
 // pt_cloud.comp main (:84-123) and its bump() (:44-76), privatised. Geometry of one workgroup (512 lanes, 8 waves):
 //   strip   pixel columns [c0, c0 + 16): a pixel (x, y) stamps around (nx, ny) = (x, H - dic(depth)), i.e. map columns
 //           x - L .. x + L - 1 with L <= 20: the strip's taps land in map columns [c0 - 20, c0 + 36) - the LDS image's 56 columns;
-//   band    map rows [r0, r0 + 64): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
-//           of each bump that fall into its own band; bands make the grid ~W/16 x H/64 = 320 workgroups at 640 x 480 and keep
-//           the image at 21 KB, several workgroups per CU.
+//   band    map rows [r0, r0 + band_h): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
+//           of each bump that fall into its own band; band_h <= 96 chosen per frame size so that the grid is ONE round of the chip (640 x 480 on 256 CUs:
+//           40 strips x 6 bands of 80 rows); the image is at most 32 KB.
 // A wave takes four pixel rows at a time: its 64 lanes compute the 4 x 16 pixels (the shader's arithmetic, one IEEE
 // operation per operator), then the wave stamps the bump pixels one at a time (ballot + readlane: wave-uniform target),
 // lane t owning taps t, t + 64, ... of the bump. The tap HEIGHTS sit in registers: a terrain tap depends on the pixel's row only
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t*
 // the tap loop: 0.56-0.65 ms per frame against 2.0-2.3 for the global-atomic form; it waited for one L2 round trip per 64 taps.)
 // Ball pixels add their position to 64-bit sums in LDS (band 0 only: once per pixel), flushed once per workgroup.
 #define SC_CW 16
-#define SC_BH 64
+#define SC_BH 96   // most map rows a workgroup's LDS image holds; the launch picks band_h <= SC_BH (yh_scene_create)
 #define SC_HALO 20
 #define SC_LDW 84   // 56 columns used; 84 = 64 + 20: a wave's 3.2 consecutive tap rows of a terrain bump fall on 64 different banks
 #define SC_TT (4 * SC_TERRAIN_NORM * SC_TERRAIN_NORM)   // 400 taps
@@ -105,16 +106,17 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
     __shared__ uint32_t img[SC_BH * SC_LDW];
     __shared__ unsigned long long ball[300];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * SC_CW, r0 = blockIdx.y * SC_BH;
+    const int c0 = blockIdx.x * SC_CW, r0 = blockIdx.y * p.band_h;
     const bool do_balls = blockIdx.y == 0;
-    for (int i = tid; i < SC_BH * SC_LDW; i += 512) img[i] = 0u;
+    const int ncell = p.band_h * SC_LDW;
+    for (int i = tid; i < ncell; i += 512) img[i] = 0u;
     if (do_balls) for (int i = tid; i < 300; i += 512) ball[i] = 0ull;
     uint32_t rt[SC_RK];   // the robot bump, this lane's taps
 #pragma unroll
     for (int k = 0; k < SC_RK; ++k) rt[k] = p.robot_tab[lane + 64 * k];
     __syncthreads();
     const int cw = min(SC_CW, p.W - c0);
-    const int band_lo = max(r0, 1), band_hi = min(r0 + SC_BH, p.H - 1);   // rows y with 0 < y < H - 1 inside the band
+    const int band_lo = max(r0, 1), band_hi = min(r0 + p.band_h, p.H - 1);   // rows y with 0 < y < H - 1 inside the band
     const int ibase = -r0 * SC_LDW - (c0 - SC_HALO);                       // img[ibase + y * SC_LDW + x] = the cell of map (x, y)
     // FOUR pixel rows per wave and iteration (lane = 16 (row in the group) + column): the depth / class loads of 64 pixels are one
     // latency, not four, and the four rows' terrain tables are requested together before the first stamp (the first version of this loop
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512) void scene_cloud_strips(const SceneParams p) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < SC_BH * SC_LDW; i += 512) {
+    for (int i = tid; i < ncell; i += 512) {
         const uint32_t v = img[i];
         if (v) {
             const int row = i / SC_LDW, col = i - row * SC_LDW;
@@ -272,7 +274,7 @@ thread_local std::string g_scene_create_error;
 }  // namespace
 
 struct yh_scene {
-    int dev = 0, W = 0, H = 0;
+    int dev = 0, W = 0, H = 0, band_h = 64;
     hipStream_t stream = nullptr;
     hipEvent_t copied = nullptr;
     std::string err;
@@ -297,14 +299,14 @@ namespace {
 int run_scene(yh_scene* h, const uint16_t* depth_dev, const uint8_t* cls_dev, const uint32_t* frame_dev, int frame_mode, int mode) {
     SceneParams p;
     p.depth = depth_dev; p.cls_id = cls_dev; p.frame = frame_dev; p.frame_mode = frame_mode;
-    p.W = h->W; p.H = h->H; p.mode = mode;
+    p.W = h->W; p.H = h->H; p.mode = mode; p.band_h = h->band_h;
     p.terrain_tab = h->terrain_tab; p.robot_tab = h->robot_tab;
     p.map = h->map; p.world = h->world; p.conn0 = h->conn0; p.conn1 = h->conn1; p.ball_acc = h->ball_acc; p.balls = h->balls;
     const size_t npx = (size_t)h->W * h->H;
     SCHK(h, hipMemsetAsync(h->map, 0, npx * 4, h->stream));
     SCHK(h, hipMemsetAsync(h->ball_acc, 0, 300 * sizeof(long long), h->stream));
     const dim3 grid((unsigned)((h->W + 7) / 8), (unsigned)((h->H + 7) / 8)), block(8, 8);   // [80,60,1] x 8x8 at 640x480 (scene.rs:245,:256)
-    hipLaunchKernelGGL(scene_cloud_strips, dim3((unsigned)((h->W + SC_CW - 1) / SC_CW), (unsigned)((h->H + SC_BH - 1) / SC_BH)), dim3(512), 0, h->stream, p);
+    hipLaunchKernelGGL(scene_cloud_strips, dim3((unsigned)((h->W + SC_CW - 1) / SC_CW), (unsigned)((h->H + h->band_h - 1) / h->band_h)), dim3(512), 0, h->stream, p);
     hipLaunchKernelGGL(scene_balls, dim3(1), dim3(128), 0, h->stream, p);
     hipLaunchKernelGGL(scene_world, grid, block, 0, h->stream, p);
     hipLaunchKernelGGL(scene_conn1, grid, block, 0, h->stream, p);
@@ -345,6 +347,15 @@ int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** ou
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_scene_create_error = "no such HIP device (no CPU fallback)"; return YH_EHIP; }
     yh_scene* h = new yh_scene();
     h->dev = device; h->W = width; h->H = height;
+    {   // rows per workgroup of the stamping kernel: the fewest bands (<= 96 rows, the LDS image) that still give every CU at most ONE
+        // workgroup - 640 x 480 on 256 CUs: 40 strips x 6 bands of 80 rows = 240 workgroups (with 64-row bands the 320 workgroups
+        // were a round and a quarter: 0.23-0.26 ms per frame)
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const int strips = (width + SC_CW - 1) / SC_CW, bands = cus / strips > 0 ? cus / strips : 1;
+        int bh = ((height + bands - 1) / bands + 7) & ~7;
+        h->band_h = bh < 32 ? 32 : (bh > SC_BH ? SC_BH : bh);
+    }
     const size_t npx = (size_t)width * height;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
