@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void scene_tables(uint32_t* terrain, uint32_t*
 //   strip   pixel columns [c0, c0 + 16): a pixel (x, y) stamps around (nx, ny) = (x, H - dic(depth)), i.e. map columns
 //           x - L .. x + L - 1 with L <= 20: the strip's taps land in map columns [c0 - 20, c0 + 36) - the LDS image's 56 columns;
 //   band    map rows [r0, r0 + band_h): every workgroup of a strip walks ALL of the strip's pixels (16 x H: cheap) and stamps the taps
-//           of each bump that fall into its own band; band_h <= 96 chosen per frame size so that the grid is ONE round of the chip (640 x 480 on 256 CUs:
-//           40 strips x 6 bands of 80 rows); the image is at most 32 KB.
+//           of each bump that fall into its own band; band_h = 64 (320 workgroups at 640 x 480; a grid of ONE round - 80-row bands - measured slower);
+//           the image is 21 KB.
 // A wave takes four pixel rows at a time: its 64 lanes compute the 4 x 16 pixels (the shader's arithmetic, one IEEE
 // operation per operator), then the wave stamps the bump pixels one at a time (ballot + readlane: wave-uniform target),
 // lane t owning taps t, t + 64, ... of the bump. The tap HEIGHTS sit in registers: a terrain tap depends on the pixel's row only
@@ -347,15 +347,8 @@ int yh_scene_create(int32_t device, int32_t width, int32_t height, yh_scene** ou
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_scene_create_error = "no such HIP device (no CPU fallback)"; return YH_EHIP; }
     yh_scene* h = new yh_scene();
     h->dev = device; h->W = width; h->H = height;
-    {   // rows per workgroup of the stamping kernel: the fewest bands (<= 96 rows, the LDS image) that still give every CU at most ONE
-        // workgroup - 640 x 480 on 256 CUs: 40 strips x 6 bands of 80 rows = 240 workgroups (with 64-row bands the 320 workgroups
-        // were a round and a quarter: 0.23-0.26 ms per frame)
-        hipDeviceProp_t prop;
-        const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const int strips = (width + SC_CW - 1) / SC_CW, bands = cus / strips > 0 ? cus / strips : 1;
-        int bh = ((height + bands - 1) / bands + 7) & ~7;
-        h->band_h = bh < 32 ? 32 : (bh > SC_BH ? SC_BH : bh);
-    }
+    h->band_h = 64;   // map rows per workgroup of the stamping kernel. Measured at 640 x 480 (ms per frame, terrain only / robots + balls): 32 rows
+                      // 0.238 / 0.270, 64 rows 0.229 / 0.262, 80 rows (one round of the chip: 240 workgroups) 0.250 / 0.304
     const size_t npx = (size_t)width * height;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
