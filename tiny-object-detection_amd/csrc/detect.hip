@@ -352,6 +352,19 @@ __global__ __launch_bounds__(1024) void det_frame_top(const DetectParams p) {
         xb = xb > fw ? fw : xb;
         yb = yb > fh ? fh : yb;
         *(float4*)(p.det_crop + ((long long)b * p.max_dets + rank) * 4) = make_float4(xa, xb, ya, yb);
+        // (round 5) ... and its 32 mask coefficients as f32, dense: the mask kernel's 75 workgroups per frame each gathered them again out of
+        // the head rows - two dependent loads per coefficient, thirteen rounds per thread - before their first pixel
+        const int cell = d.prior / 3, a = d.prior - cell * 3;
+        const half_t* hc = p.heads + ((long long)b * p.cells + cell) * p.ldh + 12 + 3 * p.C + a * 32;
+        float* co = p.det_coef + ((long long)b * p.max_dets + rank) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = hc[q * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) co[q * 8 + e] = (float)v[e];
+        }
     }
 }
 
@@ -362,41 +375,70 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     __shared__ float4 crop[YH_DETS_MAX];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nd = p.det_count[b];
-    for (int i = tid; i < nd * 32; i += 256) {
-        const int d = i >> 5, k = i & 31;
-        const int pr = p.dets[(long long)b * p.max_dets + d].prior, cell = pr / 3, a = pr - cell * 3;
-        coef[i] = (float)p.heads[((long long)b * p.cells + cell) * p.ldh + 12 + 3 * p.C + a * 32 + k];
-    }
-    for (int d = tid; d < nd; d += 256) crop[d] = *(const float4*)(p.det_crop + ((long long)b * p.max_dets + d) * 4);
+    for (int i = tid; i < nd * 32; i += 256) coef[i] = p.det_coef[(long long)b * p.max_dets * 32 + i];   // (written by det_frame_top)
+    // (round 5) which detections can touch this workgroup's pixels at all: its 256 pixels are rows y_lo .. y_hi of the prototype map, and a
+    // detection whose crop window misses those rows is all zeros here - four such detections cost a wave one dword store, not four crop
+    // tests and ballots (on a noise frame three quarters of the (workgroup, detection) pairs: 0.082 -> ... ms at batch 64)
+    __shared__ unsigned rel[YH_DETS_MAX / 32];
+    if (tid < YH_DETS_MAX / 32) rel[tid] = 0u;
     __syncthreads();
     const int npx = p.hp * p.wp;
+    {
+        const int p_lo = blockIdx.x * 256, p_hi = min(p_lo + 255, npx - 1);
+        const float y_lo = (float)(p_lo / p.wp), y_hi = (float)(p_hi / p.wp);
+        for (int d = tid; d < nd; d += 256) {
+            const float4 c = *(const float4*)(p.det_crop + ((long long)b * p.max_dets + d) * 4);
+            crop[d] = c;
+            if (y_hi >= c.z && y_lo < c.w) atomicOr(&rel[d >> 5], 1u << (d & 31));   // some row y in [y_lo, y_hi] has c.z <= y < c.w
+        }
+    }
+    __syncthreads();
     const int px = blockIdx.x * 256 + tid;
-    if (px >= npx) return;
+    const bool live = px < npx;
     const int y = px / p.wp, x = px - y * p.wp;
     const float fx = (float)x, fy = (float)y;
     float pv[32];
-    const half_t* pp = p.proto + ((long long)b * npx + px) * 32;
+    const half_t* pp = p.proto + ((long long)b * npx + (live ? px : 0)) * 32;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const half8 v = *(const half8*)(pp + q * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[q * 8 + e] = (float)v[e];
     }
-    uint8_t* mo = p.masks + (long long)b * p.max_dets * npx + px;
+    // Round 5: FOUR detections per store instruction. A lane decides one pixel of one detection; written a byte per lane that is a 64-byte
+    // store per wave and detection - 1.9 M store instructions for the 122 MB of a batch-64 step, which is what the kernel waited for
+    // (0.098 ms alone on the chip at the end of the step). The wave's 64 decisions of a detection are one ballot; lane (j, q) = (lane >> 4,
+    // lane & 15) then writes pixels 4 q .. 4 q + 3 of detection d + j as ONE dword (bit i of a nibble -> byte i: a multiplication by
+    // 0x00204081 and a mask), so a wave stores 4 x 64 bytes at once. Same bytes; hp * wp is a multiple of 4 (hp and wp are even: the
+    // prototypes are a x2 upsample), so a dword is wholly inside the mask or wholly past its end.
+    const int lane = tid & 63, lj = lane >> 4, lq = lane & 15;
+    const int wave_px0 = px - lane;
+    uint8_t* mo = p.masks + (long long)b * p.max_dets * npx + wave_px0 + 4 * lq;
+    const bool dword_live = wave_px0 + 4 * lq < npx;
     // small batches: the detections are dealt over gridDim.z groups so that more than hp*wp/256
     // workgroups exist (one frame: 75 workgroups on 256 CUs otherwise)
     const int per = (p.max_dets + (int)gridDim.z - 1) / (int)gridDim.z;
     const int d0 = (int)blockIdx.z * per, d1 = d0 + per < nd ? d0 + per : nd;
-    for (int d = d0; d < d1; ++d) {
-        const float4 c = crop[d];
-        const bool inside = fx >= c.x && fx < c.y && fy >= c.z && fy < c.w;
-        float acc = 0.0f;
-        if (__ballot(inside) != 0ull) {   // wave-uniform: no lane of these 64 pixels lies in the crop window -> all zeros
-            const float* co = coef + d * 32;
+    for (int d = d0; d < d1; d += 4) {
+        unsigned long long m[4];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) acc = __fmaf_rn(pv[k], co[k], acc);
+        for (int j = 0; j < 4; ++j) {
+            m[j] = 0ull;
+            if (d + j < d1 && ((rel[(d + j) >> 5] >> ((d + j) & 31)) & 1u)) {   // (wave-uniform)
+                const float4 c = crop[d + j];
+                const bool inside = live && fx >= c.x && fx < c.y && fy >= c.z && fy < c.w;
+                float acc = 0.0f;
+                if (__ballot(inside) != 0ull) {   // wave-uniform: no lane of these 64 pixels lies in the crop window -> all zeros
+                    const float* co = coef + (d + j) * 32;
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) acc = __fmaf_rn(pv[k], co[k], acc);
+                }
+                m[j] = __ballot(inside && acc > 0.0f);
+            }
         }
-        mo[(long long)d * npx] = (uint8_t)((inside && acc > 0.0f) ? 1 : 0);
+        const unsigned long long mine = lj == 0 ? m[0] : (lj == 1 ? m[1] : (lj == 2 ? m[2] : m[3]));
+        const unsigned nib = (unsigned)(mine >> (4 * lq)) & 15u;
+        if (dword_live && d + lj < d1) *(unsigned*)(mo + (long long)(d + lj) * npx) = (nib * 0x00204081u) & 0x01010101u;
     }
 }
 

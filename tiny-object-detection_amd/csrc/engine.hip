@@ -777,6 +777,7 @@ int alloc_tail(yh_engine* h) {
     AL(det_count, int, N);
     AL(dets, yh_detection, (size_t)N * h->cfg.max_dets);
     AL(det_crop, float, (size_t)N * h->cfg.max_dets * 4);
+    AL(det_coef, float, (size_t)N * h->cfg.max_dets * 32);
     AL(masks, uint8_t, (size_t)N * h->cfg.max_dets * h->hp * h->wp);
 #undef AL
     if ((rc = dev_alloc(h, &p, sizeof(float) * (size_t)h->P * 4))) return rc;

@@ -247,6 +247,7 @@ struct DetectParams {
     int* det_count;       // [n]
     yh_detection* dets;   // [n][max_dets]
     float* det_crop;      // [n][max_dets][4]  xa, xb, ya, yb
+    float* det_coef;      // [n][max_dets][32] the detections' mask coefficients as f32 (det_frame_top -> det_masks)
     uint8_t* masks;       // [n][max_dets][hp*wp]
 };
 hipError_t launch_detect(const DetectParams& p, hipStream_t s);
