@@ -2131,7 +2131,8 @@ int yh_debug_set_cu_mask(yh_engine* h, const uint32_t* mask, int32_t n_words) {
     h->graphs.clear();
     hipStream_t ns = nullptr, nd = nullptr;
     HIPCHK(h, hipExtStreamCreateWithCUMask(&ns, (uint32_t)n_words, mask));
-    HIPCHK(h, hipExtStreamCreateWithCUMask(&nd, (uint32_t)n_words, mask));
+    const hipError_t e2 = hipExtStreamCreateWithCUMask(&nd, (uint32_t)n_words, mask);
+    if (e2 != hipSuccess) { hipStreamDestroy(ns); return h->fail(YH_EHIP, std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e2)); }   // (the handle keeps its streams)
     hipStreamDestroy(h->stream); hipStreamDestroy(h->side);
     h->stream = ns; h->side = nd;
     return YH_OK;
