@@ -75,48 +75,71 @@ __global__ __launch_bounds__(192) void det_softmax_cand(const DetectParams p) {
     }
 }
 
-// K1 for a compile-time class count (the 81-class configuration): logits staged as f16 (what the
-// heads hold anyway: 2 C bytes per lane instead of 4 C, so 15 instead of 6 waves fit a CU) and the
-// C exponentials kept in registers between the sum and the threshold pass. Same arithmetic, same
-// order, same candidates as the generic kernel above.
+// K1 for a compile-time class count (the 81-class configuration). The conf part of 64 head rows is copied to LDS AS IT LIES
+// IN THE ROW (dwords 6 .. 127 = halves 12 .. 255, coalesced dword loads, conflict-free dword stores; the row pitch of 123 dwords
+// is odd), wave k of the three takes anchor k and lane l the row l: its 81 logits are halves 81 k .. 81 k + 80 of the row image,
+// read one ds_read_u16 each (123 l + const: every lane its own bank). Same arithmetic, same order, same candidates as the
+// generic kernel above; the candidates' order inside a class list is free (K2 ranks by (score, prior)).
+// The reads are `volatile` on purpose: left to merge them the compiler builds wide ds_read_b128 / ds_read2_b32, and that form
+// together with its packed-f32 exponentials gave scores 1e-7 .. 1e-3 off in lanes 48-63 of a wave under the graph-replayed
+// two-stream step (tools/study/tail_vs_oracle_repeat.py; the guard is
+// tests/test_gpu_fullsize.py::test_tail_exact_and_heads_repeatable_after_idle_gaps_on_the_two_stream_graph).
+#define YH_K1_RS 123   // dwords per row image in LDS (122 used)
 template <int C>
 __global__ __launch_bounds__(192) void det_softmax_cand_c(const DetectParams p) {
-    __shared__ __attribute__((aligned(16))) half_t zh[192 * C];  // [192][C]
-    const int tid = threadIdx.x, b = blockIdx.y;
+    static_assert((12 + 3 * C + 1) / 2 - 6 <= YH_K1_RS - 1 && C % 2 == 1, "row image: dwords 6 .. (12 + 3 C) / 2");
+    constexpr int ND = (12 + 3 * C + 1) / 2 - 6;   // 122 dwords of a row hold its 3 C logits (and one half of the next field)
+    __shared__ uint32_t zw[YH_K1_ROWS * YH_K1_RS];
+    const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, k = tid >> 6;
     const int c0 = blockIdx.x * YH_K1_ROWS;
     const half_t* rows = p.heads + ((long long)b * p.cells + c0) * p.ldh;
     const int nrows = p.cells - c0 < YH_K1_ROWS ? p.cells - c0 : YH_K1_ROWS;
-    const int chunks = p.ldh / 8;
-    for (int i = tid; i < nrows * chunks; i += 192) {
-        const int rl = i / chunks, j = i - rl * chunks;
-        const half8 v = *(const half8*)(rows + (long long)rl * p.ldh + j * 8);
+    // wave k copies rows k, k + 3, ...: four rows' loads in flight, then their stores
+    for (int r0 = k; r0 < nrows; r0 += 12) {
+        uint32_t v0[4], v1[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int q = j * 8 + e - 12;
-            if (q >= 0 && q < 3 * C) zh[rl * 3 * C + q] = v[e];
+        for (int u = 0; u < 4; ++u) {
+            const int rl = r0 + 3 * u;
+            const uint32_t* src = (const uint32_t*)(rows + (long long)(rl < nrows ? rl : r0) * p.ldh) + 6;
+            v0[u] = src[lane];
+            v1[u] = src[lane < ND - 64 ? 64 + lane : 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rl = r0 + 3 * u;
+            if (rl < nrows) {
+                zw[rl * YH_K1_RS + lane] = v0[u];
+                if (lane < ND - 64) zw[rl * YH_K1_RS + 64 + lane] = v1[u];
+            }
         }
     }
     __syncthreads();
-    const bool valid = tid / 3 < nrows;
-    const int pr = (c0 + tid / 3) * 3 + tid % 3;
-    const half_t* z = zh + tid * C;
+    const bool valid = lane < nrows;
+    const int pr = (c0 + lane) * 3 + k;
+    typedef const volatile __attribute__((address_space(3))) half_t lds_logit_t;   // (a plain volatile pointer became 81 flat loads)
+    lds_logit_t* z = (lds_logit_t*)zw + lane * (2 * YH_K1_RS) + C * k;
     float e[C];
     float s = 1.0f;
     if (valid) {
-        float m = (float)z[0];
 #pragma unroll
-        for (int c = 1; c < C; ++c) { const float v = (float)z[c]; m = v > m ? v : m; }
+        for (int c = 0; c < C; ++c) e[c] = (float)z[c];
+        float m = e[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) m = e[c] > m ? e[c] : m;
         s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { e[c] = spec_expf(__fsub_rn((float)z[c], m)); s = __fadd_rn(s, e[c]); }
+        for (int c = 0; c < C; ++c) { e[c] = spec_expf(__fsub_rn(e[c], m)); s = __fadd_rn(s, e[c]); }
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) e[c] = 0.0f;
     }
-    const int lane = tid & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // (rounding is monotone and conf_thresh is a float: e / s <= conf_thresh in real numbers => fl(e / s) <= conf_thresh. `lim` sits
+    // 2^-10 below fl(conf_thresh * s), so e < lim proves "no candidate" without the division; every other case takes the exact test)
+    const float lim = valid ? __fmul_rn(__fmul_rn(p.conf_thresh, s), 0.9990234375f) : 3.0e38f;
 #pragma unroll
     for (int c = 1; c < C; ++c) {
+        if (__ballot(e[c] >= lim) == 0ull) continue;  // wave-uniform: no lane can pass
         const float pc = valid ? __fdiv_rn(e[c], s) : 0.0f;
         const bool hit = pc > p.conf_thresh;
         const unsigned long long mask = __ballot(hit);
