@@ -4,7 +4,7 @@ buffer or a miscompiled kernel.)  Two 550x550 noise frames are alternated, so an
 data; `idle` seconds of idle device before each step.  Also checks that heads and prototypes of a frame repeat bit for bit two
 steps later.  A differing detection is printed with its place in K1's grid (workgroup, lane, wave).
 
-    python tools/study/tail_vs_oracle_repeat.py [reps = 6] [idle_s = 0] [modes = eager1,eager2,graph1,graph2t,graph2]
+    python tools/study/tail_vs_oracle_repeat.py [reps = 6] [idle_s = 0] [modes = eager1,eager2,graph1,graph2t,graph2] [frames per step = 1]
 
 What it found: tools/study/k1_wide_reads_packed_exp.patch (a K1 whose LDS reads the compiler merged into wide ones) fails in mode
 graph2 with idle >= 2 s in about every second step, always in lanes 48-63 of a wave; the shipped K1 does not.
@@ -19,14 +19,15 @@ from oracle import oracle
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 idle = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # seconds of idle device before each step
 S = 550
-imgs = [np.random.default_rng(5 + k).integers(0, 256, (1, S, S, 3), dtype=np.uint8) for k in range(2)]   # alternated: data left over from the step before is WRONG data
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # frames per step (the tail is checked on the first four)
+imgs = [np.random.default_rng(5 + k).integers(0, 256, (N, S, S, 3), dtype=np.uint8) for k in range(2)]   # alternated: data left over from the step before is WRONG data
 MODES = {"eager1": ("eager, one stream", dict(use_graph=False, tune=dict(headfork_maxb=0, tailfork=0))),
          "eager2": ("eager, two streams", dict(use_graph=False)),
          "graph1": ("graph, one stream (+ the dummy branch)", dict(use_graph=True, tune=dict(headfork_maxb=0, tailfork=0))),
          "graph2t": ("graph, tail fork only", dict(use_graph=True, tune=dict(headfork_maxb=0))),
          "graph2": ("graph, two streams", dict(use_graph=True))}
 for label, kw in (MODES[m] for m in (sys.argv[3].split(",") if len(sys.argv) > 3 else MODES)):
-    eng = ya.Engine(input_size=S, max_batch=8, **kw)
+    eng = ya.Engine(input_size=S, max_batch=max(8, N), **kw)
     blob = eng.generate_weights(seed=1)
     eng.load_weights(blob)
     net = oracle.Net(50, S, 81, blob=blob)
@@ -42,6 +43,11 @@ for label, kw in (MODES[m] for m in (sys.argv[3].split(",") if len(sys.argv) > 3
                 nd = int(np.count_nonzero(x.view(np.uint32) != y.view(np.uint32)))
                 if nd: print(f"{label} rep {r}: {name} differs from the same frame's earlier step in {nd} of {x.size} values", flush=True)
         hist[r & 1] = got
+        for f in range(1, min(N, 4)):   # further frames of the step: counted only
+            fd, fm = eng.detections(f)
+            od, om = oracle.detect(got[0][f], got[1][f], got[2][f], got[3][f], pri)
+            nb = sum(1 for x, y in zip(fd, od) if (x["class_id"], x["prior"], x["score"], x["box"]) != (y["class_id"], y["prior"], y["score"], y["box"])) + abs(len(fd) - len(od))
+            if nb or not np.array_equal(fm, om): print(f"{label} rep {r}: frame {f}: {nb} detections differ, masks equal: {np.array_equal(fm, om)}", flush=True)
         odets, omasks = oracle.detect(got[0][0], got[1][0], got[2][0], got[3][0], pri)
         a = [(d["class_id"], d["prior"], d["score"]) for d in dets]
         b = [(d["class_id"], d["prior"], d["score"]) for d in odets]
