@@ -299,8 +299,10 @@ def test_dual_source_conv_vs_oracle_on_reals(eng, oracle):
     assert np.all(np.abs(y - yo) <= 2.0 ** -10 * np.maximum(np.abs(yo), 1.0) + 1e-3)
 
 
-@pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13)])
+@pytest.mark.parametrize("h,w,ho,wo", [(18, 18, 35, 35), (35, 35, 69, 69), (4, 4, 8, 8), (5, 7, 9, 13),
+                                       (69, 69, 138, 138), (6, 10, 12, 20), (9, 5, 18, 10), (2, 2, 4, 4), (1, 1, 2, 2), (3, 1, 6, 2)])
 def test_bilinear_bit_exact(eng, oracle, h, w, ho, wo):
+    """(the exact x2 cases run bilinear2x_f16: four source pixels shared by 4 x 2 outputs of a lane, borders on the generic path)"""
     x = f16(np.random.default_rng(h).normal(0, 2, (2, h, w, 64)))
     assert np.array_equal(eng.op_bilinear(x, ho, wo), oracle.bilinear(x, ho, wo, f16=True))
 

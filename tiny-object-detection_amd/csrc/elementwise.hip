@@ -114,6 +114,90 @@ __global__ __launch_bounds__(256) void bilinear_f16(const half_t* __restrict__ x
     }
 }
 
+// The exact x2 case (ho = 2 h, wo = 2 w: the protonet's upsample). bilinear_f16 above fetches four source pixels per output - 2.5 GB
+// through L2 -> CU for a 624 MB tensor at batch 64, which is what bounds it (the vector-memory path of the CU, not HBM). At x2 the
+// outputs (2 j + 1, 2 j + 2) x (4 i .. 4 i + 3) read source columns j, j + 1 and rows 2 i - 1 .. 2 i + 2 only: a lane makes those 4 x 2
+// outputs of one 8-channel group from 8 fetches (one per output instead of four). Column slots: 0 = output column 0 alone,
+// 1 .. w - 1 = the pairs, w = output column 2 w - 1 alone; the two single columns and the first / last block of rows (where the
+// generic formula clamps) take the generic per-output path. Every output is the SAME expression of the same four source values
+// and the same weights as in bilinear_f16 (weights from the same float formula): bit-identical.
+__device__ __forceinline__ void bil_emit(const half8 p00, const half8 p01, const half8 p10, const half8 p11, float lx, float ly,
+                                         half_t* __restrict__ y, uint8_t* __restrict__ y8, const float* inv8, long long yo) {
+    const float hx = 1.0f - lx, hy = 1.0f - ly;
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float top = hx * (float)p00[e] + lx * (float)p01[e];
+        const float bot = hx * (float)p10[e] + lx * (float)p11[e];
+        o[e] = (half_t)(hy * top + ly * bot);
+    }
+    if (y) *(half8*)(y + yo) = o;
+    if (y8) {
+        const unsigned lo = e4m3_pack4((float)o[0] * inv8[0], (float)o[1] * inv8[1], (float)o[2] * inv8[2], (float)o[3] * inv8[3]);
+        const unsigned hi = e4m3_pack4((float)o[4] * inv8[4], (float)o[5] * inv8[5], (float)o[6] * inv8[6], (float)o[7] * inv8[7]);
+        *(uint2*)(y8 + yo) = make_uint2(lo, hi);
+    }
+}
+__global__ __launch_bounds__(256) void bilinear2x_f16(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                      int h, int w, int c8, long long x_img_stride, long long y_img_stride,
+                                                      uint8_t* __restrict__ y8, const float* __restrict__ y8_inv) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (w + 1) * c8) return;
+    const int ho = 2 * h, wo = 2 * w;
+    const int jp = t / c8, cg = t - jp * c8, b = blockIdx.z, oy0 = blockIdx.y * BIL_ROWS;
+    const half_t* xb = x + b * x_img_stride + cg * 8;
+    const int c = c8 * 8;
+    float inv8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) inv8[e] = y8 ? y8_inv[cg * 8 + e] : 1.0f;
+    const int ox_first = jp == 0 ? 0 : 2 * jp - 1, ncol = (jp == 0 || jp == w) ? 1 : 2;
+    const int i2 = oy0 / 2;   // source rows i2 - 1 .. i2 + 2
+    const bool interior = ncol == 2 && i2 >= 1 && i2 + 2 <= h - 1;   // (oy0 + 3 <= ho - 1 follows; blockIdx.y is wave-uniform, jp nearly)
+    if (interior) {
+        half8 q[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            q[r][0] = *(const half8*)(xb + ((long long)(i2 - 1 + r) * w + (jp - 1)) * c);
+            q[r][1] = *(const half8*)(xb + ((long long)(i2 - 1 + r) * w + jp) * c);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = oy0 + r;
+            float fy = ((float)oy + 0.5f) * 0.5f - 0.5f;   // (h / ho = 0.5 exactly; the generic kernel's sy)
+            const int y0 = (int)fy;                          // = i2 - 1 + (r + 1) / 2, y1 = y0 + 1: no clamp in an interior block
+            const float ly = fy - (float)y0;
+            const int a = (r + 1) >> 1;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int ox = ox_first + cc;
+                const float fx = ((float)ox + 0.5f) * 0.5f - 0.5f;   // = jp - 1 + 0.25 / 0.75: x0 = jp - 1, x1 = jp
+                const float lx = fx - (float)(jp - 1);
+                bil_emit(q[a][0], q[a][1], q[a + 1][0], q[a + 1][1], lx, ly, y, y8, inv8, b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8);
+            }
+        }
+        return;
+    }
+    const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+    for (int r = 0; r < BIL_ROWS; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= ho) break;
+        float fy = ((float)oy + 0.5f) * sy - 0.5f;
+        fy = fy < 0.0f ? 0.0f : fy;
+        const int y0 = (int)fy, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        const float ly = fy - (float)y0;
+        for (int cc = 0; cc < ncol; ++cc) {
+            const int ox = ox_first + cc;
+            float fx = ((float)ox + 0.5f) * sx - 0.5f;
+            fx = fx < 0.0f ? 0.0f : fx;
+            const int x0 = (int)fx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+            const float lx = fx - (float)x0;
+            bil_emit(*(const half8*)(xb + ((long long)y0 * w + x0) * c), *(const half8*)(xb + ((long long)y0 * w + x1) * c),
+                     *(const half8*)(xb + ((long long)y1 * w + x0) * c), *(const half8*)(xb + ((long long)y1 * w + x1) * c), lx, ly, y, y8, inv8,
+                     b * y_img_stride + (((long long)oy * wo + ox) * c8 + cg) * 8);
+        }
+    }
+}
+
 // Output reads (not on the hot path): split the fused head rows into loc / conf / mask as f32.
 __global__ __launch_bounds__(256) void split_heads_f32(const half_t* __restrict__ heads, long long rows, int ldh,
                                                        int C, float* loc, float* conf, float* mask) {
@@ -231,7 +315,10 @@ hipError_t launch_maxpool3x3s2(const half_t* x, half_t* y, int n, int h, int w, 
 }
 hipError_t launch_bilinear(const half_t* x, half_t* y, int n, int h, int w, int c, int ho, int wo,
                            long long xs, long long ys, hipStream_t s, uint8_t* y8, const float* y8_inv) {
-    hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)((ho + BIL_ROWS - 1) / BIL_ROWS), (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
+    if (ho == 2 * h && wo == 2 * w && w >= 2)
+        hipLaunchKernelGGL(bilinear2x_f16, dim3(nblk((long long)(w + 1) * (c / 8)), (unsigned)((ho + BIL_ROWS - 1) / BIL_ROWS), (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, xs, ys, y8, y8_inv);
+    else
+        hipLaunchKernelGGL(bilinear_f16, dim3(nblk((long long)wo * (c / 8)), (unsigned)((ho + BIL_ROWS - 1) / BIL_ROWS), (unsigned)n), dim3(256), 0, s, x, y, h, w, c / 8, ho, wo, xs, ys, y8, y8_inv);
     return hipGetLastError();
 }
 hipError_t launch_quantize_rows_e4m3(const half_t* x, uint8_t* y, int rows, int K, int C, const float* col_scale, const float* inv_scale_rows, hipStream_t s) {
