@@ -567,7 +567,7 @@ int build_graph_spec(yh_engine* h) {
     if ((rc = new_buf(h, "up4", cfeat[1].h, cfeat[1].w, 256, &up4))) return rc;
     if ((rc = new_buf(h, "lat3", cfeat[1].h, cfeat[1].w, 256, &lat3))) return rc;
     auto bil = [&](const char* name, const Buf& in, const Buf& out) {
-        Op o; o.kind = OP_BILINEAR; o.name = name; o.label = std::string("bilinear_f16:") + name; o.in = in; o.out = out;
+        Op o; o.kind = OP_BILINEAR; o.name = name; o.label = std::string(out.h == 2 * in.h && out.w == 2 * in.w && in.w >= 2 ? "bilinear2x_f16:" : "bilinear_f16:") + name; o.in = in; o.out = out;
         o.P = out.h; o.Q = out.w;
         o.bytes_per_img = 2.0 * in.c * ((double)in.h * in.w + (double)out.h * out.w);
         h->ops.push_back(o);

@@ -7,14 +7,18 @@ steps later.  A differing detection is printed with its place in K1's grid (work
     python tools/study/tail_vs_oracle_repeat.py [reps = 6] [idle_s = 0] [modes = eager1,eager2,graph1,graph2t,graph2] [frames per step = 1]
 
 What it found: tools/study/k1_wide_reads_packed_exp.patch (a K1 whose LDS reads the compiler merged into wide ones) fails in mode
-graph2 with idle >= 2 s in about every second step, always in lanes 48-63 of a wave; the shipped K1 does not.
-Uses the oracle: a test tool, not product code."""
+graph2 with idle >= 2 s in about a third of the steps (the rate moves with the box; clean runs of 12-16 steps happen), always in
+lanes 48-63 of a wave; the forms with one ds_read_u16 per logit have not failed in 116 steps.
+YH_STUDY_LIB=<path> runs a study build of the library instead of the in-tree one. Uses the oracle: a test tool, not product code."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tiny-object-detection_amd")); sys.path.insert(0, ROOT)
 import yolact_amd as ya
 from oracle import oracle
+if os.environ.get("YH_STUDY_LIB"):   # a study build of the kernel library instead of the in-tree one (this TOOL reads the variable, the library reads none)
+    from yolact_amd import capi
+    capi.lib_path = lambda: os.path.abspath(os.environ["YH_STUDY_LIB"])
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 idle = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # seconds of idle device before each step
