@@ -213,7 +213,7 @@ def test_fpn_upsample_in_the_lateral_epilogue_is_bitwise_the_two_kernel_form(bui
         eng.set_input(img)
         eng.evaluate()
         names = [p["name"] for p in eng.profile(with_tail=False, reps=1)]
-        assert any(n_.startswith("bilinear_f16:up") for n_ in names) == (upfuse == 0)
+        assert any(n_.startswith(("bilinear_f16:up", "bilinear2x_f16:up")) for n_ in names) == (upfuse == 0)
         outs.append([eng.tensor(t) for t in ("lat5", "lat4", "lat3", "p3")] + [eng.output(i) for i in range(4)])
         if upfuse:
             with pytest.raises(ya.YhError):
