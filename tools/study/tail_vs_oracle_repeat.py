@@ -8,7 +8,7 @@ steps later.  A differing detection is printed with its place in K1's grid (work
 
 What it found: tools/study/k1_wide_reads_packed_exp.patch (a K1 whose LDS reads the compiler merged into wide ones) fails in mode
 graph2 with idle >= 2 s in about a third of the steps (the rate moves with the box; clean runs of 12-16 steps happen), always in
-lanes 48-63 of a wave; the forms with one ds_read_u16 per logit have not failed in 116 steps.
+lanes 48-63 of a wave; the forms with one ds_read_u16 per logit have not failed in 176 steps.
 YH_STUDY_LIB=<path> runs a study build of the library instead of the in-tree one. Uses the oracle: a test tool, not product code."""
 import os, sys, time
 import numpy as np
