@@ -476,7 +476,8 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
     switch (stage) {
         case 0: {   // (the candidate counters are zero on entry: K2 re-zeroes what it consumes)
             const dim3 grid((unsigned)((p.cells + YH_K1_ROWS - 1) / YH_K1_ROWS), (unsigned)p.n);
-            if (p.C == 81 && !p.k1_generic) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
+            // (the row-image form reads dwords 6 .. 127 of a head row: rows of at least 256 halves, dword aligned - ldh = 352 at 81 classes)
+            if (p.C == 81 && !p.k1_generic && p.ldh >= 256 && p.ldh % 2 == 0) hipLaunchKernelGGL(det_softmax_cand_c<81>, grid, dim3(192), 0, s, p);
             else hipLaunchKernelGGL(det_softmax_cand, grid, dim3(192), (size_t)192 * p.C * sizeof(float), s, p);
             break;
         }
