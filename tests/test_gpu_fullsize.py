@@ -175,9 +175,9 @@ def test_second_stream_changes_no_bit_over_many_steps(built):
 
 def test_tail_exact_and_heads_repeatable_after_idle_gaps_on_the_two_stream_graph(eng550, oracle):
     """Round 5 found a compiled form of the candidate kernel (K1 with merged wide LDS reads AND the compiler's packed-f32
-    exponentials) whose scores came out 1e-7 .. 1e-3 off - in lanes 48-63 of a wave only, only in the graph-replayed
-    two-stream step at batch 1, only after the device had been idle for a second or two, a few detections in every second step
-    (tools/study/tail_vs_oracle_repeat.py). No other test in the suite has all three conditions except, by
+    exponentials) whose scores came out 1e-7 .. 1e-3 off - in lanes 48-63 of a wave only, only while proto3's launch ran beside
+    it in the graph-replayed two-stream step at batch 1, a few detections in every second or third step once the device had idled
+    (tools/study/tail_vs_oracle_repeat.py; detect.hip is built without packed-f32 arithmetic since). No other test in the suite has all three conditions except, by
     accident, the one-frame test above. This is the deliberate form: two frames alternated (so anything left over from the step
     before is WRONG data), 2 s of idle device before every step, and per step (a) the tail bit-exact on the engine's own head
     outputs, (b) heads and prototypes bit-equal to the same frame's earlier step."""
