@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void det_masks(const DetectParams p) {
     const bool dword_live = wave_px0 + 4 * lq < npx;
     // small batches: the detections are dealt over gridDim.z groups so that more than hp*wp/256
     // workgroups exist (one frame: 75 workgroups on 256 CUs otherwise)
-    const int per = (p.max_dets + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int per = ((p.max_dets + (int)gridDim.z - 1) / (int)gridDim.z + 3) & ~3;   // (whole groups of four detections: a group is one store)
     const int d0 = (int)blockIdx.z * per, d1 = d0 + per < nd ? d0 + per : nd;
     for (int d = d0; d < d1; d += 4) {
         unsigned long long m[4];
@@ -483,7 +483,7 @@ hipError_t launch_detect_stage(const DetectParams& p, int stage, hipStream_t s) 
         }
         case 1: hipLaunchKernelGGL(det_class_nms, dim3((unsigned)(p.n * (p.C - 1))), dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL(det_frame_top, dim3((unsigned)p.n), dim3(1024), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 4u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(det_masks, dim3((unsigned)((p.hp * p.wp + 255) / 256), (unsigned)p.n, p.n <= 2 ? 8u : (p.n <= 8 ? 2u : 1u)), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
