@@ -4,11 +4,11 @@ buffer or a miscompiled kernel.)  Two 550x550 noise frames are alternated, so an
 data; `idle` seconds of idle device before each step.  Also checks that heads and prototypes of a frame repeat bit for bit two
 steps later.  A differing detection is printed with its place in K1's grid (workgroup, lane, wave).
 
-    python tools/study/tail_vs_oracle_repeat.py [reps = 6] [idle_s = 0] [modes = eager1,eager2,graph1,graph2t,graph2] [frames per step = 1]
+    python tools/study/tail_vs_oracle_repeat.py [reps = 6] [idle_s = 0] [modes = eager1,eager2,graph1,graph2t,graph2] [frames per step = 1] [r50_550_f16 | r101_700_fp8]
 
 What it found: tools/study/k1_wide_reads_packed_exp.patch (a K1 whose LDS reads the compiler merged into wide ones) fails in mode
 graph2 with idle >= 2 s in about a third of the steps (the rate moves with the box; clean runs of 12-16 steps happen), always in
-lanes 48-63 of a wave; the forms with one ds_read_u16 per logit have not failed in 176 steps.
+lanes 48-63 of a wave; the forms with one ds_read_u16 per logit have not failed in 400 steps.
 YH_STUDY_LIB=<path> runs a study build of the library instead of the in-tree one. Uses the oracle: a test tool, not product code."""
 import os, sys, time
 import numpy as np
@@ -22,7 +22,8 @@ if os.environ.get("YH_STUDY_LIB"):   # a study build of the kernel library inste
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 idle = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # seconds of idle device before each step
-S = 550
+CONFIG = sys.argv[5] if len(sys.argv) > 5 else "r50_550_f16"
+S = 700 if CONFIG == "r101_700_fp8" else 550
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # frames per step (the tail is checked on the first four)
 imgs = [np.random.default_rng(5 + k).integers(0, 256, (N, S, S, 3), dtype=np.uint8) for k in range(2)]   # alternated: data left over from the step before is WRONG data
 MODES = {"eager1": ("eager, one stream", dict(use_graph=False, tune=dict(headfork_maxb=0, tailfork=0))),
@@ -31,11 +32,14 @@ MODES = {"eager1": ("eager, one stream", dict(use_graph=False, tune=dict(headfor
          "graph2t": ("graph, tail fork only", dict(use_graph=True, tune=dict(headfork_maxb=0))),
          "graph2": ("graph, two streams", dict(use_graph=True))}
 for label, kw in (MODES[m] for m in (sys.argv[3].split(",") if len(sys.argv) > 3 else MODES)):
+    if CONFIG == "r101_700_fp8":   # configs[4]'s engine: R101, 700 x 700, E4M3 operands on the K-heavy 3x3 layers
+        kw = dict(kw, backbone=101, precision=ya.PRECISION_FP8)
     eng = ya.Engine(input_size=S, max_batch=max(8, N), **kw)
     blob = eng.generate_weights(seed=1)
     eng.load_weights(blob)
-    net = oracle.Net(50, S, 81, blob=blob)
-    pri = net.priors()
+    if CONFIG == "r101_700_fp8":
+        eng.set_input(imgs[0]); eng.fp8_calibrate()
+    pri = eng.priors()
     prev = None; prev_scores = None; hist = [None, None]
     for r in range(reps):
         time.sleep(idle)
